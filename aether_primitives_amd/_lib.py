@@ -1,0 +1,125 @@
+"""ctypes binding of libaether_hip.so (include/aether_hip.h).
+
+The library is the product; this module only declares its prototypes.  There is
+no CPU fallback: if the shared object is missing or does not load, importing
+fails loudly with instructions (build with `python -c "import __graft_entry__ as
+g; g.build()"` or `make -C aether_primitives_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaether_hip.so")
+
+OK = 0
+E_LEN, E_ARG, E_ALIGN, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+
+vp, sz, f32, i32 = C.c_void_p, C.c_size_t, C.c_float, C.c_int
+pvp = C.POINTER(C.c_void_p)
+psz = C.POINTER(C.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/aether_hip.h declaration by declaration
+PROTOTYPES = {
+    "aeth_last_error": (C.c_char_p, []),
+    "aeth_version": (i32, []),
+    "aeth_device_count": (i32, [C.POINTER(i32)]),
+    "aeth_ctx_create": (i32, [i32, pvp]),
+    "aeth_ctx_create_on_stream": (i32, [i32, vp, pvp]),
+    "aeth_ctx_destroy": (i32, [vp]),
+    "aeth_ctx_sync": (i32, [vp]),
+    "aeth_ctx_stream": (vp, [vp]),
+    "aeth_ctx_device": (i32, [vp]),
+    "aeth_dev_alloc": (i32, [vp, sz, pvp]),
+    "aeth_dev_free": (i32, [vp, vp]),
+    "aeth_upload": (i32, [vp, vp, vp, sz]),
+    "aeth_download": (i32, [vp, vp, vp, sz]),
+    "aeth_copy_dev": (i32, [vp, vp, vp, sz]),
+    "aeth_event_create": (i32, [vp, pvp]),
+    "aeth_event_destroy": (i32, [vp]),
+    "aeth_event_record": (i32, [vp]),
+    "aeth_event_sync": (i32, [vp]),
+    "aeth_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
+    "aeth_vec_scale": (i32, [vp, vp, sz, f32]),
+    "aeth_vec_mul": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_vec_div": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_vec_conj": (i32, [vp, vp, sz]),
+    "aeth_vec_add": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_vec_sub": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_vec_mirror": (i32, [vp, vp, sz]),
+    "aeth_vec_clone": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_vec_zero": (i32, [vp, vp, sz]),
+    "aeth_vec_mirror_frames": (i32, [vp, vp, sz, sz]),
+    "aeth_host_vec_scale": (i32, [vp, vp, sz, f32]),
+    "aeth_host_vec_mul": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_host_vec_div": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_host_vec_conj": (i32, [vp, vp, sz]),
+    "aeth_host_vec_add": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_host_vec_sub": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_host_vec_mirror": (i32, [vp, vp, sz]),
+    "aeth_host_vec_clone": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_host_vec_zero": (i32, [vp, vp, sz]),
+    "aeth_scale_factor": (f32, [i32, sz, f32]),
+    "aeth_scale_apply": (i32, [vp, i32, f32, vp, sz]),
+    "aeth_fft_create": (i32, [vp, sz, sz, pvp]),
+    "aeth_fft_destroy": (i32, [vp]),
+    "aeth_fft_len": (sz, [vp]),
+    "aeth_fft_algorithm": (C.c_char_p, [vp]),
+    "aeth_fft_exec": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
+    "aeth_fft_exec_host": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
+    "aeth_fft_exec_tmp_host": (i32, [vp, vp, sz, i32, i32, f32, pvp]),
+    "aeth_fft_exec_tmp": (i32, [vp, vp, sz, sz, i32, i32, f32, pvp]),
+    "aeth_fft_mul_ifft": (i32, [vp, vp, sz, sz, vp, sz, i32, f32, i32, f32]),
+    "aeth_fir_create": (i32, [vp, vp, sz, sz, pvp]),
+    "aeth_fir_destroy": (i32, [vp]),
+    "aeth_fir_ntaps": (sz, [vp]),
+    "aeth_fir_fft_len": (sz, [vp]),
+    "aeth_fir_hop": (sz, [vp]),
+    "aeth_fir_exec": (i32, [vp, vp, vp, sz, vp]),
+    "aeth_fir_exec_host": (i32, [vp, vp, vp, sz, vp]),
+    "aeth_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),
+    "aeth_interpolate_frames": (i32, [vp, vp, sz, sz, vp, sz, sz, i32, psz]),
+    "aeth_host_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),
+    "aeth_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
+    "aeth_host_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
+}
+
+_lib = None
+
+
+class AetherError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class LengthMismatch(AetherError, AssertionError):
+    """AETH_E_LEN: the reference panics (assert_eq!) with this message."""
+
+
+def load():
+    """Load libaether_hip.so; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP backend is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C aether_primitives_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = load().aeth_last_error().decode("utf-8", "replace")
+    if rc == E_LEN:
+        raise LengthMismatch(rc, msg)
+    raise AetherError(rc, msg)

@@ -1,0 +1,466 @@
+// aeth_fft.hip -- batched complex FFT behind the reference's `Fft` trait
+// (src/fft.rs:48-77) / `Cfft` (src/fft.rs:134-235).
+//
+// Kernel paths (chosen per length at plan time):
+//   stockham_pow2   N = 2..4096, power of two: register radix-16/8/4 Stockham, one
+//                   frame per T = N/P lanes, data exchanged through LDS between
+//                   passes, twiddles held in registers across a persistent loop over
+//                   frames.  16 B/sample of HBM traffic (8 R + 8 W), scale fused.
+//   stockham_mixed  N <= 4096 with prime factors <= 61: one workgroup per frame,
+//                   LDS ping-pong, radix 2/3/4/5/7/8 butterflies (3 and 5 in
+//                   sum/difference form so that constant inputs give exactly-zero
+//                   bins, as the reference's own FFT tests expect: fft.rs:93-104,
+//                   vecops.rs:443-463 at N=100), generic O(r^2) for other primes.
+//   fourstep_pow2   N = 2^13..2^24: N1 x N2 decomposition, two launches through the
+//                   plan's scratch (BASELINE config 5, N = 65536 = 256 x 256).
+//   bluestein       everything else: chirp-z through a power-of-two convolution.
+#include "aeth_internal.h"
+#include "aeth_fft_core.h"
+#include "aeth_fft_plan.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace aeth::fftk;
+
+namespace {
+
+// =============================== stockham_pow2 ================================
+template <class C, bool SWAP>
+__global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
+                                                          const cf *__restrict__ twN, size_t batch, float scale)
+{
+    __shared__ cf lds_all[C::LDS_ELEMS];
+    const int tid = threadIdx.x % C::T;
+    const int fl = threadIdx.x / C::T;
+    cf *lds = lds_all + fl * C::LDS_FRAME;
+
+    cf tw[C::TW];
+    load_twiddles<C>(tw, twN, tid);
+
+    const size_t ngroups = (batch + C::F - 1) / C::F;
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const size_t frame = g * C::F + fl;
+        const bool active = frame < batch;
+        const cf *src = in + frame * C::N + tid;
+        cf *dst = out + frame * C::N + tid;
+        cf w[C::P];
+#pragma unroll
+        for (int m = 0; m < C::P; m++) {
+            cf v = active ? src[m * C::T] : mk(0.f, 0.f);
+            w[m] = SWAP ? cswap(v) : v;
+        }
+        fft_in_regs<C>(w, tw, lds, tid);
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < C::P; m++) {
+                cf v = cscale(w[m], scale);
+                dst[m * C::T] = SWAP ? cswap(v) : v;
+            }
+        }
+    }
+}
+
+template <class C>
+int launch_pow2(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+{
+    const aeth_ctx *ctx = plan->ctx;
+    size_t ngroups = (batch + C::F - 1) / C::F;
+    size_t cap = (size_t)ctx->num_cus * 8;
+    int grid = (int)(ngroups < cap ? ngroups : cap);
+    if (grid < 1) grid = 1;
+    if (sign > 0)
+        hipLaunchKernelGGL((fft_pow2_kernel<C, true>), dim3(grid), dim3(C::WG), 0, ctx->stream, in, out, plan->tw_dev, batch, scale);
+    else
+        hipLaunchKernelGGL((fft_pow2_kernel<C, false>), dim3(grid), dim3(C::WG), 0, ctx->stream, in, out, plan->tw_dev, batch, scale);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+int dispatch_pow2(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+{
+#define AETH_BODY(NN) return launch_pow2<typename CfgFor<NN>::type>(plan, in, out, batch, sign, scale)
+    AETH_POW2_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
+#undef AETH_BODY
+}
+
+// =============================== stockham_mixed ===============================
+constexpr int kMixedWG = 256;
+constexpr int kMaxFactors = 16;
+
+struct MixedDesc {
+    int n;
+    int nfac;
+    int fac[kMaxFactors];
+};
+
+__device__ __forceinline__ cf tw_at(const cf *__restrict__ twN, int idx) { return twN[idx]; }
+
+// radix-3 / radix-5 in sum/difference form (exact zeros for constant input)
+__device__ __forceinline__ void bfly3(cf &a, cf &b, cf &c)
+{
+    const float s60 = 0.86602540378443864676f;
+    cf t1 = cadd(b, c), t2 = csub(b, c);
+    cf y0 = cadd(a, t1);
+    cf h = mk(y0.x + (-1.5f) * t1.x, y0.y + (-1.5f) * t1.y);
+    cf jt = cscale(mul_mj(t2), s60);
+    a = y0;
+    b = cadd(h, jt);
+    c = csub(h, jt);
+}
+
+__device__ __forceinline__ void bfly5(cf &x0, cf &x1, cf &x2, cf &x3, cf &x4)
+{
+    const float ca = -1.25f, cb = 0.55901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    cf t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+    cf t5 = cadd(t1, t2);
+    cf y0 = cadd(x0, t5);
+    cf m1 = mk(y0.x + ca * t5.x, y0.y + ca * t5.y);
+    cf m2 = cscale(csub(t1, t2), cb);
+    cf a1 = cadd(m1, m2), a2 = csub(m1, m2);
+    cf b1 = mk(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    cf b2 = mk(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    cf jb1 = mul_mj(b1), jb2 = mul_mj(b2);
+    x0 = y0;
+    x1 = cadd(a1, jb1);
+    x4 = csub(a1, jb1);
+    x2 = cadd(a2, jb2);
+    x3 = csub(a2, jb2);
+}
+
+__device__ __forceinline__ void bfly7(cf (&u)[7], const cf *__restrict__ twN, int n)
+{
+    // symmetric-pair form: y_k = x0 + sum_m c(km) (x_m + x_{7-m}) - j s(km) (x_m - x_{7-m})
+    cf s[3], d[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) { s[m] = cadd(u[m + 1], u[6 - m]); d[m] = csub(u[m + 1], u[6 - m]); }
+    cf x0 = u[0];
+    u[0] = cadd(cadd(x0, s[0]), cadd(s[1], s[2]));
+    const int step = n / 7;
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+        cf re = x0, im = mk(0.f, 0.f);
+#pragma unroll
+        for (int m = 1; m <= 3; m++) {
+            cf wkm = twN[((k * m) % 7) * step];       // (cos, -sin)
+            re.x += wkm.x * s[m - 1].x; re.y += wkm.x * s[m - 1].y;
+            im.x += wkm.y * d[m - 1].x; im.y += wkm.y * d[m - 1].y;   // wkm.y = -sin
+        }
+        // x_m w^m + x_{7-m} w^{-m} = c*s_m + j*(w.y)*d_m  with w = c + j*w.y
+        cf jim = mk(-im.y, im.x);
+        u[k] = cadd(re, jim);
+        u[7 - k] = csub(re, jim);
+    }
+}
+
+template <bool SWAP>
+__global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *out,
+                                                              const cf *__restrict__ twN, MixedDesc d,
+                                                              size_t batch, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *bufA = reinterpret_cast<cf *>(smem_raw);
+    cf *bufB = bufA + d.n;
+    const int n = d.n;
+    for (size_t frame = blockIdx.x; frame < batch; frame += gridDim.x) {
+        const cf *gin = in + frame * (size_t)n;
+        cf *gout = out + frame * (size_t)n;
+        // stage the frame (lets every pass read LDS; keeps in-place launches safe)
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += kMixedWG) {
+            cf v = gin[e];
+            bufA[e] = SWAP ? cswap(v) : v;
+        }
+        __syncthreads();
+        if (d.nfac == 0) {      // len == 1: the DFT is the identity
+            for (int e = threadIdx.x; e < n; e += kMixedWG) {
+                cf v = cscale(bufA[e], scale);
+                gout[e] = SWAP ? cswap(v) : v;
+            }
+            continue;
+        }
+        cf *X = bufA, *Y = bufB;
+        int p = 1;
+        for (int s = 0; s < d.nfac; s++) {
+            const int R = d.fac[s];
+            const int m = n / R;
+            const int step = n / (p * R);
+            const bool last = (s == d.nfac - 1);
+            for (int i = threadIdx.x; i < m; i += kMixedWG) {
+                const int k = i % p;
+                const int j = (i - k) * R + k;
+                auto ld = [&](int r) -> cf {
+                    cf v = X[i + r * m];
+                    return (p > 1 && r > 0) ? cmul(v, twN[r * k * step]) : v;
+                };
+                auto st = [&](int r, cf v) {
+                    if (last) {
+                        v = cscale(v, scale);
+                        gout[j + r * p] = SWAP ? cswap(v) : v;
+                    } else Y[j + r * p] = v;
+                };
+                if (R == 2) {
+                    cf u[2] = {ld(0), ld(1)};
+                    Bfly<2>::run(u);
+                    st(0, u[0]); st(1, u[1]);
+                } else if (R == 4) {
+                    cf u[4] = {ld(0), ld(1), ld(2), ld(3)};
+                    Bfly<4>::run(u);
+                    st(0, u[0]); st(1, u[1]); st(2, u[2]); st(3, u[3]);
+                } else if (R == 8) {
+                    cf u[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) u[r] = ld(r);
+                    Bfly<8>::run(u);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) st(r, u[r]);
+                } else if (R == 3) {
+                    cf a = ld(0), b = ld(1), c = ld(2);
+                    bfly3(a, b, c);
+                    st(0, a); st(1, b); st(2, c);
+                } else if (R == 5) {
+                    cf a = ld(0), b = ld(1), c = ld(2), e = ld(3), f = ld(4);
+                    bfly5(a, b, c, e, f);
+                    st(0, a); st(1, b); st(2, c); st(3, e); st(4, f);
+                } else if (R == 7) {
+                    cf u[7];
+#pragma unroll
+                    for (int r = 0; r < 7; r++) u[r] = ld(r);
+                    bfly7(u, twN, n);
+#pragma unroll
+                    for (int r = 0; r < 7; r++) st(r, u[r]);
+                } else {
+                    // generic prime radix: O(R^2), inputs re-read from LDS
+                    const int rstep = n / R;
+                    for (int q = 0; q < R; q++) {
+                        cf acc = ld(0);
+                        for (int r = 1; r < R; r++) acc = cadd(acc, cmul(ld(r), twN[((r * q) % R) * rstep]));
+                        st(q, acc);
+                    }
+                }
+            }
+            __syncthreads();
+            cf *t = X; X = Y; Y = t;
+            p *= R;
+        }
+    }
+}
+
+int launch_mixed(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+{
+    const aeth_ctx *ctx = plan->ctx;
+    MixedDesc d;
+    d.n = (int)plan->len;
+    d.nfac = (int)plan->factors.size();
+    for (int i = 0; i < d.nfac; i++) d.fac[i] = plan->factors[i];
+    size_t cap = (size_t)ctx->num_cus * 4;
+    int grid = (int)(batch < cap ? batch : cap);
+    if (grid < 1) grid = 1;
+    const size_t shmem = 2 * plan->len * sizeof(cf);
+    if (sign > 0)
+        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, in, out, plan->tw_dev, d, batch, scale);
+    else
+        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, in, out, plan->tw_dev, d, batch, scale);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+// ================================ planning ====================================
+bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
+
+// radix schedule for stockham_mixed: 8s and 4s first, then 2, 3, 5, 7, other primes
+bool factorize_mixed(size_t n, std::vector<int> &fac)
+{
+    fac.clear();
+    while (n % 8 == 0) { fac.push_back(8); n /= 8; }
+    while (n % 4 == 0) { fac.push_back(4); n /= 4; }
+    while (n % 2 == 0) { fac.push_back(2); n /= 2; }
+    for (size_t f = 3; f <= 61 && n > 1; f += 2)
+        while (n % f == 0) { fac.push_back((int)f); n /= f; }
+    return n == 1 && fac.size() <= (size_t)kMaxFactors;
+}
+
+int make_twiddles(aeth_ctx *ctx, size_t n, cf **out_dev)
+{
+    std::vector<cf> h(n ? n : 1);
+    for (size_t k = 0; k < n; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)n;
+        h[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    AETH_HIP(hipMalloc((void **)out_dev, h.size() * sizeof(cf)));
+    AETH_HIP(hipMemcpyAsync(*out_dev, h.data(), h.size() * sizeof(cf), hipMemcpyHostToDevice, ctx->stream));
+    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    return AETH_OK;
+}
+
+}  // namespace
+
+namespace aeth {
+
+int fft_ensure_tmp(aeth_fft *plan, size_t elems)
+{
+    if (plan->tmp_elems >= elems) return AETH_OK;
+    if (plan->tmp_dev) {
+        AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+        AETH_HIP(hipFree(plan->tmp_dev));
+        plan->tmp_dev = nullptr;
+        plan->tmp_elems = 0;
+    }
+    AETH_HIP(hipMalloc((void **)&plan->tmp_dev, elems * sizeof(cf)));
+    plan->tmp_elems = elems;
+    return AETH_OK;
+}
+
+// device-pointer transform of `batch` frames; in may equal out
+int fft_run(aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+{
+    if (batch == 0 || plan->len == 0) return AETH_OK;
+    switch (plan->algo) {
+    case FFT_ALGO_POW2:  return dispatch_pow2(plan, in, out, batch, sign, scale);
+    case FFT_ALGO_MIXED: return launch_mixed(plan, in, out, batch, sign, scale);
+    case FFT_ALGO_FOURSTEP: return fft_run_fourstep(plan, in, out, batch, sign, scale);
+    case FFT_ALGO_BLUESTEIN: return fft_run_bluestein(plan, in, out, batch, sign, scale);
+    default: return set_error(AETH_E_UNSUPPORTED, "no kernel path for length %zu", plan->len);
+    }
+}
+
+}  // namespace aeth
+
+extern "C" {
+
+int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
+{
+    AETH_REQUIRE(ctx && out, AETH_E_ARG, "null argument");
+    *out = nullptr;
+    AETH_REQUIRE(len >= 1, AETH_E_ARG, "FFT length must be >= 1");
+    AETH_REQUIRE(len <= ((size_t)1 << 24), AETH_E_UNSUPPORTED, "FFT length %zu > 2^24", len);
+    aeth::DeviceGuard g(ctx->device);
+    aeth_fft *p = new (std::nothrow) aeth_fft();
+    AETH_REQUIRE(p, AETH_E_NOMEM, "out of host memory");
+    p->ctx = ctx;
+    p->len = len;
+    if (max_batch < 1) max_batch = 1;
+    int rc = AETH_OK;
+    if (len == 1) {
+        p->algo = aeth::FFT_ALGO_MIXED;      // zero passes: copy + scale
+        p->factors.clear();
+        p->algo_name = "identity";
+    } else if (is_pow2(len) && len <= 4096) {
+        p->algo = aeth::FFT_ALGO_POW2;
+        p->algo_name = "stockham_pow2";
+    } else if (len <= 4096 && factorize_mixed(len, p->factors)) {
+        p->algo = aeth::FFT_ALGO_MIXED;
+        p->algo_name = "stockham_mixed";
+    } else if (is_pow2(len)) {
+        p->algo = aeth::FFT_ALGO_FOURSTEP;
+        p->algo_name = "fourstep_pow2";
+        rc = aeth::fft_plan_fourstep(p);
+    } else {
+        p->algo = aeth::FFT_ALGO_BLUESTEIN;
+        p->algo_name = "bluestein";
+        rc = aeth::fft_plan_bluestein(p);
+    }
+    if (rc == AETH_OK) rc = make_twiddles(ctx, len, &p->tw_dev);
+    if (rc == AETH_OK) rc = aeth::fft_ensure_tmp(p, 2 * len * max_batch);
+    if (rc == AETH_OK) {
+        hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * len * sizeof(cf), hipHostMallocDefault);
+        if (e != hipSuccess) rc = aeth::hip_fail(e, "hipHostMalloc");
+    }
+    if (rc != AETH_OK) { aeth_fft_destroy(p); return rc; }
+    *out = p;
+    return AETH_OK;
+}
+
+int aeth_fft_destroy(aeth_fft *p)
+{
+    if (!p) return AETH_OK;
+    aeth::DeviceGuard g(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    aeth::fft_plan_release_children(p);
+    if (p->tw_dev) (void)hipFree(p->tw_dev);
+    if (p->tmp_dev) (void)hipFree(p->tmp_dev);
+    if (p->tmp_host) (void)hipHostFree(p->tmp_host);
+    delete p;
+    return AETH_OK;
+}
+
+size_t aeth_fft_len(const aeth_fft *p) { return p ? p->len : 0; }
+const char *aeth_fft_algorithm(const aeth_fft *p) { return p ? p->algo_name : ""; }
+
+static int check_exec(const aeth_fft *p, int sign, int kind)
+{
+    AETH_REQUIRE(p, AETH_E_ARG, "plan is null");
+    AETH_REQUIRE(sign == AETH_SIGN_REF_FWD || sign == AETH_SIGN_REF_BWD, AETH_E_ARG, "sign must be +1 or -1");
+    AETH_REQUIRE(kind >= AETH_SCALE_NONE && kind <= AETH_SCALE_X, AETH_E_ARG, "bad scale kind %d", kind);
+    return AETH_OK;
+}
+
+int aeth_fft_exec(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out, size_t batch, int sign,
+                  int kind, float x)
+{
+    int rc = check_exec(p, sign, kind); if (rc) return rc;
+    AETH_REQUIRE(n_in == batch * p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);     /* fft.rs:163-167 */
+    if (batch == 0) return AETH_OK;
+    AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out), AETH_E_ALIGN, "pointer not 8-byte aligned");
+    const float s = aeth_scale_factor(kind, p->len, x);                     /* fft.rs:22-37, n = frame length */
+    return aeth::fft_run(p, (const cf *)in, (cf *)out, batch, sign, s);
+}
+
+int aeth_fft_exec_tmp(aeth_fft *p, const aeth_cf32 *in, size_t n_in, size_t batch, int sign, int kind, float x,
+                      const aeth_cf32 **view)
+{
+    int rc = check_exec(p, sign, kind); if (rc) return rc;
+    AETH_REQUIRE(view, AETH_E_ARG, "view is null");
+    *view = nullptr;
+    AETH_REQUIRE(n_in == batch * p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);     /* fft.rs:207-211 */
+    if (batch == 0) return AETH_OK;
+    AETH_REQUIRE(in, AETH_E_ARG, "null pointer");
+    rc = aeth::fft_ensure_tmp(p, 2 * n_in); if (rc) return rc;
+    cf *dst = p->tmp_dev + n_in;                                            /* tmp[len..], fft.rs:213 */
+    const float s = aeth_scale_factor(kind, p->len, x);
+    rc = aeth::fft_run(p, (const cf *)in, dst, batch, sign, s); if (rc) return rc;
+    *view = (const aeth_cf32 *)dst;
+    return AETH_OK;
+}
+
+int aeth_fft_exec_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out, size_t n_out, int sign,
+                       int kind, float x)
+{
+    int rc = check_exec(p, sign, kind); if (rc) return rc;
+    AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
+    AETH_REQUIRE(n_out == p->len, AETH_E_LEN, "Output and FFT must be the same length");
+    AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
+    hipStream_t st = p->ctx->stream;
+    const size_t bytes = p->len * sizeof(cf);
+    AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));   /* tmp[..len] <- input, fft.rs:168 */
+    const float s = aeth_scale_factor(kind, p->len, x);
+    rc = aeth::fft_run(p, p->tmp_dev, p->tmp_dev + p->len, 1, sign, s); if (rc) return rc;
+    AETH_HIP(hipMemcpyAsync(out, p->tmp_dev + p->len, bytes, hipMemcpyDeviceToHost, st));
+    AETH_HIP(hipStreamSynchronize(st));
+    return AETH_OK;
+}
+
+int aeth_fft_exec_tmp_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, int sign, int kind, float x,
+                           const aeth_cf32 **view)
+{
+    int rc = check_exec(p, sign, kind); if (rc) return rc;
+    AETH_REQUIRE(view, AETH_E_ARG, "view is null");
+    *view = nullptr;
+    AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
+    AETH_REQUIRE(in, AETH_E_ARG, "null pointer");
+    hipStream_t st = p->ctx->stream;
+    const size_t bytes = p->len * sizeof(cf);
+    AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));
+    const float s = aeth_scale_factor(kind, p->len, x);
+    rc = aeth::fft_run(p, p->tmp_dev, p->tmp_dev + p->len, 1, sign, s); if (rc) return rc;
+    AETH_HIP(hipMemcpyAsync(p->tmp_host + p->len, p->tmp_dev + p->len, bytes, hipMemcpyDeviceToHost, st));
+    AETH_HIP(hipStreamSynchronize(st));
+    *view = (const aeth_cf32 *)(p->tmp_host + p->len);
+    return AETH_OK;
+}
+
+}  // extern "C"

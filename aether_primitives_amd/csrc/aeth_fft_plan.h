@@ -1,0 +1,43 @@
+// aeth_fft_plan.h -- the plan object behind `aeth_fft` (replaces Cfft,
+// reference src/fft.rs:134-159: two rustfft plans + tmp of 2*len).
+#pragma once
+
+#include "aeth_internal.h"
+
+#include <vector>
+
+struct aeth_fft {
+    aeth_ctx *ctx = nullptr;
+    size_t len = 0;
+    int algo = 0;
+    const char *algo_name = "";
+    float2 *tw_dev = nullptr;        // exp(-2 pi i k / len), k < len
+    float2 *tmp_dev = nullptr;       // >= 2*len*max_batch (Cfft.tmp, fft.rs:141,155)
+    size_t tmp_elems = 0;
+    float2 *tmp_host = nullptr;      // pinned 2*len: what tfwd/tbwd lend out
+    std::vector<int> factors;        // stockham_mixed radix schedule
+    // fourstep_pow2: len = n1 * n2
+    size_t n1 = 0, n2 = 0;
+    float2 *work_dev = nullptr;      // intermediate of the two launches (len * batch)
+    size_t work_elems = 0;
+    // bluestein: convolution length m (power of two), sub-plan, chirps
+    size_t blu_m = 0;
+    aeth_fft *blu_sub = nullptr;
+    float2 *blu_chirp = nullptr;     // exp(-j pi k^2 / len), k < len
+    float2 *blu_filt = nullptr;      // FFT_m of the zero-padded conjugate chirp, / m
+};
+
+namespace aeth {
+
+enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4 };
+
+int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+int fft_ensure_tmp(aeth_fft *plan, size_t elems);
+
+int fft_plan_fourstep(aeth_fft *plan);
+int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+int fft_plan_bluestein(aeth_fft *plan);
+int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+void fft_plan_release_children(aeth_fft *plan);
+
+}  // namespace aeth

@@ -1,0 +1,62 @@
+// aeth_internal.h -- shared host-side plumbing for libaether_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/aether_hip.h"
+
+struct aeth_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cus = 256;
+    // staging for the host-slice flavours: pinned host + device scratch, grown on demand
+    void *pin[2] = {nullptr, nullptr};
+    size_t pin_bytes[2] = {0, 0};
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+};
+
+namespace aeth {
+
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int hip_fail(hipError_t e, const char *what);
+
+// ensure staging slot `i` holds >= bytes (device + pinned host)
+int ctx_stage(aeth_ctx *ctx, int i, size_t bytes);
+
+inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace aeth
+
+#define AETH_HIP(call)                                              \
+    do {                                                            \
+        hipError_t e__ = (call);                                    \
+        if (e__ != hipSuccess) return aeth::hip_fail(e__, #call);   \
+    } while (0)
+
+#define AETH_REQUIRE(cond, code, ...)                               \
+    do {                                                            \
+        if (!(cond)) return aeth::set_error((code), __VA_ARGS__);   \
+    } while (0)
+
+// message texts of the reference's panics (kept verbatim for the binding)
+#define AETH_MSG_VEC_LEN "Vectors must have same length"            /* src/vecops.rs:100-104 */
+#define AETH_MSG_FFT_LEN "Input and FFT must be the same length"    /* src/fft.rs:163-167   */
+#define AETH_MSG_DECIM   "Only even decimations are supported"      /* src/sampling.rs:32-36 */

@@ -1,0 +1,300 @@
+// aeth_vecops.hip -- element-wise cf32 kernels behind trait VecOps
+// (reference: src/vecops.rs:94-177).  Compiled with -ffp-contract=off: the
+// reference is Rust, which never fuses a*b+c, and these ops must be bit-exact
+// against it (the crate's assert_evm! at -80 "dB" is tighter than 1 ulp,
+// src/lib.rs:36-47).
+//
+// HBM-bound streaming kernels: 16-byte (2 x cf32) accesses per lane where
+// alignment allows, 8-byte otherwise; grid capped at 8 workgroups per CU with a
+// grid-stride loop, 4 independent accesses in flight per lane.
+#include "aeth_internal.h"
+
+namespace {
+
+enum Op { OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SCALE, OP_CONJ, OP_CLONE, OP_ZERO };
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+
+// ---- per-element arithmetic, spelled exactly as num-complex 0.2 does ---------
+template <int OP>
+__device__ __forceinline__ float2 apply2(float2 a, float2 b, float s)
+{
+    if constexpr (OP == OP_ADD) return make_float2(a.x + b.x, a.y + b.y);          // vecops.rs:140
+    if constexpr (OP == OP_SUB) return make_float2(a.x - b.x, a.y - b.y);          // vecops.rs:153
+    if constexpr (OP == OP_MUL)                                                     // vecops.rs:110
+        return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    if constexpr (OP == OP_DIV) {                                                   // vecops.rs:123
+        float ns = b.x * b.x + b.y * b.y;
+        float re = a.x * b.x + a.y * b.y;
+        float im = a.y * b.x - a.x * b.y;
+        return make_float2(re / ns, im / ns);
+    }
+    if constexpr (OP == OP_SCALE) return make_float2(a.x * s, a.y * s);             // vecops.rs:95
+    if constexpr (OP == OP_CONJ) return make_float2(a.x, -a.y);                     // vecops.rs:128
+    if constexpr (OP == OP_CLONE) return b;                                         // vecops.rs:170
+    return make_float2(0.0f, 0.0f);                                                 // vecops.rs:175
+}
+
+template <int OP>
+__device__ __forceinline__ float4 apply4(float4 a, float4 b, float s)
+{
+    float2 lo = apply2<OP>(make_float2(a.x, a.y), make_float2(b.x, b.y), s);
+    float2 hi = apply2<OP>(make_float2(a.z, a.w), make_float2(b.z, b.w), s);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <int OP> constexpr bool reads_self() { return OP != OP_CLONE && OP != OP_ZERO; }
+template <int OP> constexpr bool reads_other() { return OP == OP_ADD || OP == OP_SUB || OP == OP_MUL || OP == OP_DIV || OP == OP_CLONE; }
+
+// V = float4 (two samples) or float2 (one sample)
+template <int OP, typename V>
+__global__ __launch_bounds__(kBlock) void ew_kernel(V *__restrict__ self, const V *__restrict__ other,
+                                                    size_t n, float s)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + (kUnroll - 1) * stride < n; i += kUnroll * stride) {
+        V a[kUnroll], b[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            if constexpr (reads_self<OP>()) a[u] = self[i + u * stride];
+            if constexpr (reads_other<OP>()) b[u] = other[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            if constexpr (sizeof(V) == 16) self[i + u * stride] = apply4<OP>(a[u], b[u], s);
+            else self[i + u * stride] = apply2<OP>(a[u], b[u], s);
+        }
+    }
+    for (; i < n; i += stride) {
+        V a, b;
+        if constexpr (reads_self<OP>()) a = self[i];
+        if constexpr (reads_other<OP>()) b = other[i];
+        if constexpr (sizeof(V) == 16) self[i] = apply4<OP>(a, b, s);
+        else self[i] = apply2<OP>(a, b, s);
+    }
+}
+
+inline int grid_for(const aeth_ctx *ctx, size_t items)
+{
+    size_t blocks = (items + (size_t)kBlock * kUnroll - 1) / ((size_t)kBlock * kUnroll);
+    size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int OP>
+int launch_ew(aeth_ctx *ctx, aeth_cf32 *self, const aeth_cf32 *other, size_t n, float s)
+{
+    if (n == 0) return AETH_OK;
+    float2 *a = reinterpret_cast<float2 *>(self);
+    const float2 *b = reinterpret_cast<const float2 *>(other);
+    const bool two = reads_other<OP>();
+    const uintptr_t ma = reinterpret_cast<uintptr_t>(a) & 15u;
+    const uintptr_t mb = two ? (reinterpret_cast<uintptr_t>(b) & 15u) : ma;
+    if (ma == mb) {
+        // same phase: peel one sample if the base sits on an odd 8-byte slot, then 16-byte body
+        size_t head = (ma != 0 && n > 0) ? 1 : 0;
+        size_t body = (n - head) / 2;
+        size_t tail = (n - head) - 2 * body;
+        if (head)
+            hipLaunchKernelGGL((ew_kernel<OP, float2>), dim3(1), dim3(kBlock), 0, ctx->stream, a, b, (size_t)1, s);
+        if (body)
+            hipLaunchKernelGGL((ew_kernel<OP, float4>), dim3(grid_for(ctx, body)), dim3(kBlock), 0, ctx->stream,
+                               reinterpret_cast<float4 *>(a + head),
+                               reinterpret_cast<const float4 *>(two ? b + head : nullptr), body, s);
+        if (tail)
+            hipLaunchKernelGGL((ew_kernel<OP, float2>), dim3(1), dim3(kBlock), 0, ctx->stream,
+                               a + head + 2 * body, two ? b + head + 2 * body : nullptr, (size_t)1, s);
+    } else {
+        hipLaunchKernelGGL((ew_kernel<OP, float2>), dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, a, b, n, s);
+    }
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+// ---- mirror: swap(x, x+mid), mid = len/2, per frame (vecops.rs:157-161) --------
+template <typename V>
+__global__ __launch_bounds__(kBlock) void mirror_kernel(V *__restrict__ x, size_t frame_stride_v, size_t mid_v,
+                                                        size_t batch)
+{
+    // items = batch * mid_v, item -> (frame, j)
+    const size_t total = batch * mid_v;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        size_t f = i / mid_v, j = i - f * mid_v;
+        V *p = x + f * frame_stride_v + j;
+        V lo = p[0], hi = p[mid_v];
+        p[0] = hi;
+        p[mid_v] = lo;
+    }
+}
+
+int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch)
+{
+    const size_t mid = frame_len / 2;
+    if (mid == 0 || batch == 0) return AETH_OK;
+    float2 *x = reinterpret_cast<float2 *>(self);
+    const bool vec = aeth::aligned16(x) && (mid % 2 == 0) && (frame_len % 2 == 0);
+    if (vec) {
+        size_t total = batch * (mid / 2);
+        hipLaunchKernelGGL((mirror_kernel<float4>), dim3(grid_for(ctx, total * kUnroll)), dim3(kBlock), 0, ctx->stream,
+                           reinterpret_cast<float4 *>(x), frame_len / 2, mid / 2, batch);
+    } else {
+        size_t total = batch * mid;
+        hipLaunchKernelGGL((mirror_kernel<float2>), dim3(grid_for(ctx, total * kUnroll)), dim3(kBlock), 0, ctx->stream,
+                           x, frame_len, mid, batch);
+    }
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+int check_unary(aeth_ctx *ctx, const void *self, size_t n)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    AETH_REQUIRE(self || n == 0, AETH_E_ARG, "self is null");
+    AETH_REQUIRE(aeth::aligned8(self), AETH_E_ALIGN, "self not 8-byte aligned");
+    return AETH_OK;
+}
+
+int check_binary(aeth_ctx *ctx, const void *self, size_t n, const void *other, size_t n_other)
+{
+    int rc = check_unary(ctx, self, n);
+    if (rc) return rc;
+    AETH_REQUIRE(n == n_other, AETH_E_LEN, AETH_MSG_VEC_LEN);
+    AETH_REQUIRE(other || n == 0, AETH_E_ARG, "other is null");
+    AETH_REQUIRE(aeth::aligned8(other), AETH_E_ALIGN, "other not 8-byte aligned");
+    return AETH_OK;
+}
+
+// host-slice flavour: H2D -> kernel -> D2H, synchronous (the literal trait call)
+template <typename F>
+int host_roundtrip(aeth_ctx *ctx, aeth_cf32 *self, size_t n, const aeth_cf32 *other, bool upload_self, F &&run)
+{
+    if (n == 0) return AETH_OK;
+    const size_t bytes = n * sizeof(aeth_cf32);
+    int rc = aeth::ctx_stage(ctx, 0, bytes);
+    if (rc) return rc;
+    if (other) { rc = aeth::ctx_stage(ctx, 1, bytes); if (rc) return rc; }
+    if (upload_self) AETH_HIP(hipMemcpyAsync(ctx->stage[0], self, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (other) AETH_HIP(hipMemcpyAsync(ctx->stage[1], other, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = run((aeth_cf32 *)ctx->stage[0], (const aeth_cf32 *)ctx->stage[1]);
+    if (rc) return rc;
+    AETH_HIP(hipMemcpyAsync(self, ctx->stage[0], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    return AETH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aeth_vec_scale(aeth_ctx *ctx, aeth_cf32 *x, size_t n, float s)
+{
+    int rc = check_unary(ctx, x, n); if (rc) return rc;
+    return launch_ew<OP_SCALE>(ctx, x, nullptr, n, s);
+}
+int aeth_vec_conj(aeth_ctx *ctx, aeth_cf32 *x, size_t n)
+{
+    int rc = check_unary(ctx, x, n); if (rc) return rc;
+    return launch_ew<OP_CONJ>(ctx, x, nullptr, n, 0.f);
+}
+int aeth_vec_zero(aeth_ctx *ctx, aeth_cf32 *x, size_t n)
+{
+    int rc = check_unary(ctx, x, n); if (rc) return rc;
+    return launch_ew<OP_ZERO>(ctx, x, nullptr, n, 0.f);
+}
+int aeth_vec_mirror(aeth_ctx *ctx, aeth_cf32 *x, size_t n)
+{
+    int rc = check_unary(ctx, x, n); if (rc) return rc;
+    return launch_mirror(ctx, x, n, 1);
+}
+int aeth_vec_mirror_frames(aeth_ctx *ctx, aeth_cf32 *x, size_t frame_len, size_t batch)
+{
+    int rc = check_unary(ctx, x, frame_len * batch); if (rc) return rc;
+    return launch_mirror(ctx, x, frame_len, batch);
+}
+int aeth_vec_add(aeth_ctx *ctx, aeth_cf32 *a, size_t n, const aeth_cf32 *b, size_t nb)
+{
+    int rc = check_binary(ctx, a, n, b, nb); if (rc) return rc;
+    return launch_ew<OP_ADD>(ctx, a, b, n, 0.f);
+}
+int aeth_vec_sub(aeth_ctx *ctx, aeth_cf32 *a, size_t n, const aeth_cf32 *b, size_t nb)
+{
+    int rc = check_binary(ctx, a, n, b, nb); if (rc) return rc;
+    return launch_ew<OP_SUB>(ctx, a, b, n, 0.f);
+}
+int aeth_vec_mul(aeth_ctx *ctx, aeth_cf32 *a, size_t n, const aeth_cf32 *b, size_t nb)
+{
+    int rc = check_binary(ctx, a, n, b, nb); if (rc) return rc;
+    return launch_ew<OP_MUL>(ctx, a, b, n, 0.f);
+}
+int aeth_vec_div(aeth_ctx *ctx, aeth_cf32 *a, size_t n, const aeth_cf32 *b, size_t nb)
+{
+    int rc = check_binary(ctx, a, n, b, nb); if (rc) return rc;
+    return launch_ew<OP_DIV>(ctx, a, b, n, 0.f);
+}
+int aeth_vec_clone(aeth_ctx *ctx, aeth_cf32 *a, size_t n, const aeth_cf32 *b, size_t nb)
+{
+    int rc = check_binary(ctx, a, n, b, nb); if (rc) return rc;
+    return launch_ew<OP_CLONE>(ctx, a, b, n, 0.f);
+}
+
+/* Scale::scale, src/fft.rs:22-37 */
+float aeth_scale_factor(int kind, size_t n, float x)
+{
+    switch (kind) {
+    case AETH_SCALE_SN: return 1.0f / sqrtf((float)n);
+    case AETH_SCALE_N:  return 1.0f / (float)n;
+    case AETH_SCALE_X:  return x;
+    default:            return 1.0f;
+    }
+}
+
+int aeth_scale_apply(aeth_ctx *ctx, int kind, float x, aeth_cf32 *data, size_t n)
+{
+    AETH_REQUIRE(kind >= AETH_SCALE_NONE && kind <= AETH_SCALE_X, AETH_E_ARG, "bad scale kind %d", kind);
+    if (kind == AETH_SCALE_NONE) return check_unary(ctx, data, n);
+    return aeth_vec_scale(ctx, data, n, aeth_scale_factor(kind, n, x));
+}
+
+/* ---- host-slice flavours ---------------------------------------------------- */
+int aeth_host_vec_scale(aeth_ctx *ctx, aeth_cf32 *x, size_t n, float s)
+{
+    AETH_REQUIRE(ctx && (x || !n), AETH_E_ARG, "null argument");
+    return host_roundtrip(ctx, x, n, nullptr, true, [&](aeth_cf32 *d, const aeth_cf32 *) { return aeth_vec_scale(ctx, d, n, s); });
+}
+int aeth_host_vec_conj(aeth_ctx *ctx, aeth_cf32 *x, size_t n)
+{
+    AETH_REQUIRE(ctx && (x || !n), AETH_E_ARG, "null argument");
+    return host_roundtrip(ctx, x, n, nullptr, true, [&](aeth_cf32 *d, const aeth_cf32 *) { return aeth_vec_conj(ctx, d, n); });
+}
+int aeth_host_vec_zero(aeth_ctx *ctx, aeth_cf32 *x, size_t n)
+{
+    AETH_REQUIRE(ctx && (x || !n), AETH_E_ARG, "null argument");
+    return host_roundtrip(ctx, x, n, nullptr, false, [&](aeth_cf32 *d, const aeth_cf32 *) { return aeth_vec_zero(ctx, d, n); });
+}
+int aeth_host_vec_mirror(aeth_ctx *ctx, aeth_cf32 *x, size_t n)
+{
+    AETH_REQUIRE(ctx && (x || !n), AETH_E_ARG, "null argument");
+    return host_roundtrip(ctx, x, n, nullptr, true, [&](aeth_cf32 *d, const aeth_cf32 *) { return aeth_vec_mirror(ctx, d, n); });
+}
+#define AETH_HOST_BINARY(NAME, UPLOAD_SELF)                                                               \
+    int aeth_host_vec_##NAME(aeth_ctx *ctx, aeth_cf32 *a, size_t n, const aeth_cf32 *b, size_t nb)        \
+    {                                                                                                     \
+        AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");                                                     \
+        AETH_REQUIRE(n == nb, AETH_E_LEN, AETH_MSG_VEC_LEN);                                              \
+        AETH_REQUIRE((a && b) || !n, AETH_E_ARG, "null argument");                                        \
+        return host_roundtrip(ctx, a, n, b, UPLOAD_SELF, [&](aeth_cf32 *d, const aeth_cf32 *o) {          \
+            return aeth_vec_##NAME(ctx, d, n, o, n);                                                      \
+        });                                                                                               \
+    }
+AETH_HOST_BINARY(add, true)
+AETH_HOST_BINARY(sub, true)
+AETH_HOST_BINARY(mul, true)
+AETH_HOST_BINARY(div, true)
+AETH_HOST_BINARY(clone, false)
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+"""FIR by overlap-save (the reference's Fir<T>, src/fir.rs:3-22, has no filter
+method; the build defines it from the chain at benches/benches.rs:410-416)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .context import DeviceVec
+
+
+class Fir:
+    def __init__(self, ctx, taps, fft_len=2048):
+        self.ctx = ctx
+        self._lib = _lib.load()
+        taps = np.ascontiguousarray(taps, dtype=np.complex64)
+        h = C.c_void_p()
+        check(self._lib.aeth_fir_create(ctx.h, taps.ctypes.data_as(C.c_void_p), taps.size, fft_len, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self._lib.aeth_fir_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def ntaps(self): return self._lib.aeth_fir_ntaps(self.h)
+    @property
+    def fft_len(self): return self._lib.aeth_fir_fft_len(self.h)
+    @property
+    def hop(self): return self._lib.aeth_fir_hop(self.h)
+
+    def filter(self, x, out=None, hist=None):
+        """y[n] = sum_k taps[k] x[n-k]; zero initial state unless `hist` (ntaps-1 samples)."""
+        if isinstance(x, DeviceVec):
+            if out is None:
+                out = DeviceVec(self.ctx, x.n)
+            hp = hist._p() if hist is not None else None
+            check(self._lib.aeth_fir_exec(self.h, hp, x._p(), x.n, out._p()))
+            return out
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        if out is None:
+            out = np.empty_like(x)
+        hp = None
+        if hist is not None:
+            hist = np.ascontiguousarray(hist, dtype=np.complex64)
+            assert hist.size == self.ntaps - 1
+            hp = hist.ctypes.data_as(C.c_void_p)
+        check(self._lib.aeth_fir_exec_host(self.h, hp, x.ctypes.data_as(C.c_void_p), x.size,
+                                           out.ctypes.data_as(C.c_void_p)))
+        return out

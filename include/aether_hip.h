@@ -1,0 +1,211 @@
+/*
+ * aether_hip.h -- C ABI of the MI355X (gfx950) backend for the cf32 hot path of
+ * razorheadfx/aether_primitives: VecOps / Fft / FIR / sampling.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * The reference is a Rust crate; a maintainer binds these symbols from an
+ * `extern "C"` block and implements the crate's own traits on top (rust/ in
+ * this repo holds that binding; INTEGRATION.md walks through it).  Each entry
+ * point cites the reference interface (path:line in the upstream tree) it
+ * replaces.
+ *
+ * Conventions
+ *  - aeth_cf32 is bit-identical to the crate's cf32 = Complex<f32>, repr(C)
+ *    (src/lib.rs:8-12) and to HIP float2.
+ *  - Every function returns AETH_OK (0) or a negative AETH_E_* code and never
+ *    unwinds.  aeth_last_error() returns a thread-local message.  The
+ *    reference's convention is panic-on-misuse (assert_eq!, e.g.
+ *    src/vecops.rs:100-104, src/fft.rs:163-167); the binding re-raises
+ *    AETH_E_LEN as a panic with the reference's message text, which
+ *    aeth_last_error() carries verbatim.
+ *  - "dev" functions take DEVICE pointers, are ordered on the context's HIP
+ *    stream and return without waiting (aeth_ctx_sync to wait).
+ *    "host" functions take HOST slices, stage through the context's pinned
+ *    buffers and return when the result is back in the caller's slice --
+ *    the literal one-frame-per-call trait semantics (PCIe-bound; use the dev
+ *    flavour on the hot path).
+ *  - A context/plan is not thread-safe (every reference method takes
+ *    `&mut self`), but may move between threads; distinct contexts are
+ *    independent (one device + one stream each).
+ *  - Buffers: device pointers must be 8-byte aligned (AETH_E_ALIGN otherwise);
+ *    16-byte alignment enables the widest loads.
+ */
+#ifndef AETHER_HIP_H
+#define AETHER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AETH_API __attribute__((visibility("default")))
+
+/* src/lib.rs:8-12 */
+typedef struct { float re, im; } aeth_cf32;
+
+typedef struct aeth_ctx aeth_ctx;       /* device + stream + staging buffers      */
+typedef struct aeth_fft aeth_fft;       /* replaces Cfft (src/fft.rs:134-159)     */
+typedef struct aeth_fir aeth_fir;       /* gives Fir<T> (src/fir.rs:3-22) a body  */
+typedef struct aeth_event aeth_event;   /* hipEvent on the context's stream       */
+
+enum {
+    AETH_OK = 0,
+    AETH_E_LEN = -1,          /* the reference's assert_eq! length panics          */
+    AETH_E_ARG = -2,          /* null pointer, bad enum, zero length where illegal */
+    AETH_E_ALIGN = -3,        /* device pointer not 8-byte aligned                  */
+    AETH_E_HIP = -4,          /* a HIP runtime call failed (message has details)   */
+    AETH_E_NOMEM = -5,
+    AETH_E_UNSUPPORTED = -6   /* e.g. an FFT length the backend cannot plan        */
+};
+
+/* enum Scale, src/fft.rs:6-18 */
+enum { AETH_SCALE_NONE = 0, AETH_SCALE_SN = 1, AETH_SCALE_N = 2, AETH_SCALE_X = 3 };
+
+/* Sign of the DFT exponent: out[k] = sum_n in[n] * exp(sign * 2*pi*i*n*k/N).
+ * The reference plans Fft::fwd with FFTplanner::new(true) and Fft::bwd with
+ * FFTplanner::new(false) (src/fft.rs:148,150); in rustfft 3.x the argument is
+ * `inverse`, so fwd carries the +j exponent.  The binding maps
+ * fwd/ifwd/tfwd -> AETH_SIGN_REF_FWD and bwd/ibwd/tbwd -> AETH_SIGN_REF_BWD in
+ * exactly one place. */
+enum { AETH_SIGN_REF_FWD = +1, AETH_SIGN_REF_BWD = -1 };
+
+AETH_API const char *aeth_last_error(void);
+AETH_API int aeth_version(void);                     /* 0x00MMmmpp */
+AETH_API int aeth_device_count(int *count);
+
+/* ---- context ----------------------------------------------------------- */
+AETH_API int aeth_ctx_create(int device, aeth_ctx **out);
+/* borrow an existing hipStream_t (e.g. torch's current stream); not destroyed */
+AETH_API int aeth_ctx_create_on_stream(int device, void *hip_stream, aeth_ctx **out);
+AETH_API int aeth_ctx_destroy(aeth_ctx *ctx);
+AETH_API int aeth_ctx_sync(aeth_ctx *ctx);
+AETH_API void *aeth_ctx_stream(aeth_ctx *ctx);       /* hipStream_t */
+AETH_API int aeth_ctx_device(const aeth_ctx *ctx);
+
+/* ---- device memory (caller-owned; the library never keeps host pointers) -- */
+AETH_API int aeth_dev_alloc(aeth_ctx *ctx, size_t bytes, void **dptr);
+AETH_API int aeth_dev_free(aeth_ctx *ctx, void *dptr);
+AETH_API int aeth_upload(aeth_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* waits */
+AETH_API int aeth_download(aeth_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* waits */
+AETH_API int aeth_copy_dev(aeth_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* async */
+
+/* ---- timing on the context's stream (bench harness) ---------------------- */
+AETH_API int aeth_event_create(aeth_ctx *ctx, aeth_event **out);
+AETH_API int aeth_event_destroy(aeth_event *ev);
+AETH_API int aeth_event_record(aeth_event *ev);
+AETH_API int aeth_event_sync(aeth_event *ev);
+AETH_API int aeth_event_elapsed_ms(aeth_event *start, aeth_event *stop, float *ms);
+
+/* ---- VecOps, device flavour: trait VecOps, src/vecops.rs:39-89 ------------ */
+/* All in place on `self_`.  Binary ops take both lengths so the reference's
+ * "Vectors must have same length" assert (e.g. :100-104) lives on this side. */
+AETH_API int aeth_vec_scale (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, float scale);          /* :94-97   */
+AETH_API int aeth_vec_mul   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other); /* :99-112  */
+AETH_API int aeth_vec_div   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other); /* :114-125 */
+AETH_API int aeth_vec_conj  (aeth_ctx *ctx, aeth_cf32 *self_, size_t n);                       /* :127-130 */
+AETH_API int aeth_vec_add   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other); /* :132-142 */
+AETH_API int aeth_vec_sub   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other); /* :144-155 */
+AETH_API int aeth_vec_mirror(aeth_ctx *ctx, aeth_cf32 *self_, size_t n);                       /* :157-161 */
+AETH_API int aeth_vec_clone (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other); /* :163-172 */
+AETH_API int aeth_vec_zero  (aeth_ctx *ctx, aeth_cf32 *self_, size_t n);                       /* :174-177 */
+/* vec_mirror applied to each of `batch` consecutive frames of `frame_len`
+ * (the `chunks_mut(fft_len).for_each(|c| c.vec_rfft(..).vec_mirror())` idiom,
+ * src/util/plot.rs:59-61) */
+AETH_API int aeth_vec_mirror_frames(aeth_ctx *ctx, aeth_cf32 *self_, size_t frame_len, size_t batch);
+/* vec_mutate (:179-182) takes a Rust closure and stays on the host side of the binding. */
+
+/* ---- VecOps, host-slice flavour (synchronous) ----------------------------- */
+AETH_API int aeth_host_vec_scale (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, float scale);
+AETH_API int aeth_host_vec_mul   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other);
+AETH_API int aeth_host_vec_div   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other);
+AETH_API int aeth_host_vec_conj  (aeth_ctx *ctx, aeth_cf32 *self_, size_t n);
+AETH_API int aeth_host_vec_add   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other);
+AETH_API int aeth_host_vec_sub   (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other);
+AETH_API int aeth_host_vec_mirror(aeth_ctx *ctx, aeth_cf32 *self_, size_t n);
+AETH_API int aeth_host_vec_clone (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_cf32 *other, size_t n_other);
+AETH_API int aeth_host_vec_zero  (aeth_ctx *ctx, aeth_cf32 *self_, size_t n);
+
+/* ---- Scale: src/fft.rs:22-37 ---------------------------------------------- */
+/* factor exactly as the reference computes it in f32: SN -> (n as f32).sqrt().recip(),
+ * N -> (n as f32).recip(), X -> x, None -> 1 (and no pass at all). */
+AETH_API float aeth_scale_factor(int scale_kind, size_t n, float x);
+AETH_API int aeth_scale_apply(aeth_ctx *ctx, int scale_kind, float x, aeth_cf32 *data_dev, size_t n);
+
+/* ---- Fft: trait Fft src/fft.rs:48-77, struct Cfft :134-235 ----------------- */
+/* Cfft::with_len(len) (:147-158).  max_batch sizes the plan's device scratch
+ * (>= 2*len*max_batch, mirroring Cfft.tmp :141,155); exec grows it on demand. */
+AETH_API int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out);
+AETH_API int aeth_fft_destroy(aeth_fft *plan);
+AETH_API size_t aeth_fft_len(const aeth_fft *plan);                                   /* Fft::len :232-234 */
+/* text name of the kernel path chosen for this length ("stockham_pow2", ...) */
+AETH_API const char *aeth_fft_algorithm(const aeth_fft *plan);
+/* `batch` frames of len() each, device pointers, out == in => in-place
+ * (fwd/bwd :162-182, ifwd/ibwd :184-204).  n_in is the TOTAL element count of
+ * `in` and must equal batch*len ("Input and FFT must be the same length"). */
+AETH_API int aeth_fft_exec(aeth_fft *plan, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out,
+                           size_t batch, int sign, int scale_kind, float x);
+/* host slices, one frame per call: the literal trait methods. out may equal in. */
+AETH_API int aeth_fft_exec_host(aeth_fft *plan, const aeth_cf32 *in, size_t n_in,
+                                aeth_cf32 *out, size_t n_out, int sign, int scale_kind, float x);
+/* tfwd/tbwd (:206-230): transform into the plan's internal temp and lend it.
+ * *view points to host memory valid until the next call on this plan. */
+AETH_API int aeth_fft_exec_tmp_host(aeth_fft *plan, const aeth_cf32 *in, size_t n_in,
+                                    int sign, int scale_kind, float x, const aeth_cf32 **view);
+/* device flavour of the same: *view_dev is the plan's device temp */
+AETH_API int aeth_fft_exec_tmp(aeth_fft *plan, const aeth_cf32 *in, size_t n_in, size_t batch,
+                               int sign, int scale_kind, float x, const aeth_cf32 **view_dev);
+
+/* ---- frequency-domain multiply chain: benches/benches.rs:410-416 ----------- */
+/* frames.vec_rfft(fft, s_fwd).vec_mul(sig).vec_rifft(fft, s_bwd) per frame, fused into
+ * one kernel (the "correlator inplace" benchmark; also BASELINE config 4).
+ * `sig_dev` has fft_len elements.  In place on `frames_dev`. */
+AETH_API int aeth_fft_mul_ifft(aeth_fft *plan, aeth_cf32 *frames_dev, size_t n_total, size_t batch,
+                               const aeth_cf32 *sig_dev, size_t n_sig,
+                               int scale_kind_fwd, float x_fwd, int scale_kind_bwd, float x_bwd);
+
+/* ---- FIR (src/fir.rs:3-22 holds taps + scratch but no filter method) ------- */
+/* y[n] = sum_{k<ntaps} taps[k] * x[n-k] by overlap-save built from the
+ * reference's own chain rfft -> vec_mul -> rifft(Scale::N).  taps are host
+ * memory, copied.  fft_len must be a supported power of two >= 2*ntaps. */
+AETH_API int aeth_fir_create(aeth_ctx *ctx, const aeth_cf32 *taps_host, size_t ntaps,
+                             size_t fft_len, aeth_fir **out);
+AETH_API int aeth_fir_destroy(aeth_fir *fir);
+AETH_API size_t aeth_fir_ntaps(const aeth_fir *fir);
+AETH_API size_t aeth_fir_fft_len(const aeth_fir *fir);
+AETH_API size_t aeth_fir_hop(const aeth_fir *fir);      /* outputs per block (<= fft_len-ntaps+1) */
+/* n outputs for n inputs.  hist_dev: NULL => zero initial state, else the
+ * ntaps-1 samples preceding in_dev[0] (x[-(ntaps-1)] .. x[-1]).  out != in. */
+AETH_API int aeth_fir_exec(aeth_fir *fir, const aeth_cf32 *hist_dev, const aeth_cf32 *in_dev,
+                           size_t n, aeth_cf32 *out_dev);
+AETH_API int aeth_fir_exec_host(aeth_fir *fir, const aeth_cf32 *hist_host, const aeth_cf32 *in_host,
+                                size_t n, aeth_cf32 *out_host);
+
+/* ---- sampling: src/sampling.rs ---------------------------------------------- */
+/* interpolate (:7-24): writes n_src + (n_src-1)*n_between elements to dst
+ * (the Rust wrapper reserves that much spare Vec capacity, passes its end, then
+ * set_len's: the reference APPENDS, :17,:23).  compat_im != 0 reproduces
+ * `im: x1.re + i*rate.1` (:19).  n_src == 0 -> AETH_E_LEN (reference panics, :23). */
+AETH_API int aeth_interpolate(aeth_ctx *ctx, const aeth_cf32 *src_dev, size_t n_src,
+                              aeth_cf32 *dst_dev, size_t dst_capacity, size_t n_between,
+                              int compat_im, size_t *n_written);
+/* the same for `batch` independent frames of frame_len (BASELINE config 5) */
+AETH_API int aeth_interpolate_frames(aeth_ctx *ctx, const aeth_cf32 *src_dev, size_t frame_len,
+                                     size_t batch, aeth_cf32 *dst_dev, size_t dst_capacity,
+                                     size_t n_between, int compat_im, size_t *n_written);
+AETH_API int aeth_host_interpolate(aeth_ctx *ctx, const aeth_cf32 *src, size_t n_src,
+                                   aeth_cf32 *dst, size_t dst_capacity, size_t n_between,
+                                   int compat_im, size_t *n_written);
+/* downsample / downsample_sb (:28-42 / :49-62): dst[i] = src[i*(n_src/n_dst)],
+ * generic T: Copy via elem_size (1,2,4,8,16 bytes).  n_src % n_dst != 0 ->
+ * AETH_E_LEN with "Only even decimations are supported" (:32-36). */
+AETH_API int aeth_downsample(aeth_ctx *ctx, const void *src_dev, size_t n_src,
+                             void *dst_dev, size_t n_dst, size_t elem_size);
+AETH_API int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src,
+                                  void *dst, size_t n_dst, size_t elem_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AETHER_HIP_H */

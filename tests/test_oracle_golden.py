@@ -1,0 +1,190 @@
+"""CPU: pins the oracle (oracle/aeth_oracle.c) against every known-answer test the
+reference's own suite holds for the hot path (tests/golden/reference_kat.json,
+transcribed from src/vecops.rs, src/fft.rs, src/sampling.rs, src/lib.rs)."""
+import numpy as np
+import pytest
+
+from helpers import SCALE_KIND, expand, load_kat, bits_equal, rand_c64
+
+KAT = load_kat()
+
+
+def _run_vecop(o, c):
+    x = expand(c["self"])
+    op = c["op"]
+    if op == "vec_scale": return o.vec_scale(x, c["arg"])
+    if op in ("vec_mul", "vec_div", "vec_add", "vec_sub", "vec_clone"):
+        return getattr(o, op)(x, expand(c["other"]))
+    if op in ("vec_conj", "vec_mirror", "vec_zero"): return getattr(o, op)(x)
+    raise KeyError(op)
+
+
+@pytest.mark.parametrize("cid", ["vec_scale", "vec_mul", "vec_div", "vec_conj", "vec_add", "vec_sub",
+                                 "vec_mirror", "vec_clone", "vec_zero"])
+def test_vecops_kat(oracle, cid):
+    c = KAT[cid]
+    oracle.assert_evm(_run_vecop(oracle, c), expand(c["expect"]), c["evm_db"])
+
+
+def test_vec_mutate_kat(oracle):
+    c = KAT["vec_mutate"]
+    v = expand(c["self"])
+    # the closure is host-side by definition (vecops.rs:433-438): c = c.scale(x); x += 1
+    for i in range(v.size):
+        v[i:i + 1] = oracle.vec_scale(v[i:i + 1], float(i))
+    oracle.assert_evm(v, expand(c["expect"]), c["evm_db"])
+
+
+def test_doctest_chain(oracle):
+    c = KAT["vecops_doctest_chain"]
+    v, twos, ones = expand(c["self"]), expand(c["twos"]), expand(c["ones"])
+    v = oracle.vec_div(v, twos); v = oracle.vec_mul(v, twos); v = oracle.vec_zero(v)
+    v = oracle.vec_add(v, ones); v = oracle.vec_sub(v, twos); v = oracle.vec_clone(v, ones)
+    v.imag = -1.0                       # .vec_mutate(|c| c.im = -1.0)
+    v = oracle.vec_conj(v); v = oracle.vec_mirror(v)
+    oracle.assert_evm(v, expand(c["expect"]), c["evm_db"])
+
+
+@pytest.mark.parametrize("cid", ["scale_none", "scale_sn", "scale_n", "scale_x2"])
+def test_scale_kat(oracle, cid):
+    c = KAT[cid]
+    out = oracle.scale_apply(SCALE_KIND[c["scale"]], expand(c["self"]), c.get("x", 0.0))
+    oracle.assert_evm(out, expand(c["expect"]), c["evm_db"])
+
+
+def test_fft128_doctest(oracle):
+    f = oracle.Cfft(128)
+    c = KAT["fft128_ones_fwd"]
+    y = f.fwd(expand(c["self"]), SCALE_KIND[c["scale"]])
+    oracle.assert_evm(y, expand(c["expect"]), c["evm_db"])       # off-DC bins exactly zero
+    c = KAT["fft128_back_n"]
+    z = f.bwd(y, SCALE_KIND[c["scale"]])
+    oracle.assert_evm(z, expand(c["expect"]), c["evm_db"])
+    c = KAT["fft128_sn_scale2_sn"]
+    w = f.bwd(oracle.vec_scale(f.fwd(expand(c["self"]), 1), 2.0), 1)
+    oracle.assert_evm(w, expand(c["expect"]), c["evm_db"])
+
+
+@pytest.mark.parametrize("cid", ["vec_fft_roundtrip_100", "vec_rfft_roundtrip_100"])
+def test_fft100_roundtrip(oracle, cid):
+    c = KAT[cid]
+    v = expand(c["self"])
+    if "fresh" in c["op"]:
+        y = oracle.Cfft(100).fwd(v, 1); z = oracle.Cfft(100).bwd(y, 1)
+    else:
+        f = oracle.Cfft(100); z = f.bwd(f.fwd(v, 1), 1)
+    oracle.assert_evm(z, expand(c["expect"]), c["evm_db"])
+
+
+def test_cfft_variants_agree_and_check_length(oracle):
+    x = rand_c64(3, 64)
+    f = oracle.Cfft(64)
+    a = f.fwd(x, 1)
+    t = f.tmp(x, +1, 1)
+    assert t.size == 64 and bits_equal(t, a)                        # the lent slice is tmp[len..], fft.rs:213-216
+    with pytest.raises(AssertionError):
+        f.fwd(x[:63])                                               # fft.rs:163-167
+
+
+def test_fft_sign_convention_and_truth(oracle):
+    """fwd carries the +j exponent (fft.rs:148 + rustfft FFTplanner::new(inverse=true))."""
+    for n in (8, 100, 128, 2048):
+        x = rand_c64(n, n)
+        f = oracle.Cfft(n)
+        ref_fwd = np.fft.ifft(x.astype(np.complex128)) * n          # +j, unnormalised
+        ref_bwd = np.fft.fft(x.astype(np.complex128))               # -j
+        assert oracle.evm_db(f.fwd(x), ref_fwd) < -120
+        assert oracle.evm_db(f.bwd(x), ref_bwd) < -120
+        assert np.abs(oracle.fft_f64(x, +1) - ref_fwd).max() < 1e-9 * n
+    x = rand_c64(1, 12)
+    assert np.abs(oracle.dft_naive_f64(x, -1) - np.fft.fft(x.astype(np.complex128))).max() < 1e-12
+
+
+@pytest.mark.parametrize("cid", ["interpolate_2_between", "interpolate_1_between"])
+def test_interpolate_kat(oracle, cid):
+    c = KAT[cid]
+    src = expand(c["self"])
+    out = oracle.interpolate(src, c["n_between"], compat_im=True)
+    assert out.size == src.size + (src.size - 1) * c["n_between"]
+    assert bits_equal(out, expand(c["expect"]))
+    # with re == im inputs the corrected form gives the same answer (why the quirk is invisible)
+    assert bits_equal(oracle.interpolate(src, c["n_between"], compat_im=False), expand(c["expect"]))
+
+
+def test_interpolate_im_quirk(oracle):
+    """sampling.rs:19 uses x1.re as the base of the imaginary ramp."""
+    src = np.array([1 + 10j, 3 + 14j], np.complex64)
+    out = oracle.interpolate(src, 1, compat_im=True)
+    assert out[0] == np.complex64(1 + 1j) and out[1] == np.complex64(2 + 3j) and out[2] == src[1]
+    fixed = oracle.interpolate(src, 1, compat_im=False)
+    assert fixed[0] == src[0] and fixed[1] == np.complex64(2 + 12j)
+    with pytest.raises(IndexError):
+        oracle.interpolate(np.zeros(0, np.complex64), 2)
+
+
+@pytest.mark.parametrize("cid", ["downsample_21_v_7", "downsample_16_v_4", "downsample_7_v_3_fail"])
+def test_downsample_kat(oracle, cid):
+    c = KAT[cid]
+    src = np.array(c["src_ints"], np.int32)
+    if "expect_error" in c:
+        with pytest.raises(AssertionError, match=c["expect_error"]):
+            oracle.downsample(src, c["n_dst"])
+    else:
+        assert oracle.downsample(src, c["n_dst"]).tolist() == c["expect_ints"]
+
+
+@pytest.mark.parametrize("cid", ["evm_ok_equal", "evm_ok_099", "evm_ok_101", "evm_ieee754_panics",
+                                 "evm_exceeded_panics"])
+def test_assert_evm_kat(oracle, cid):
+    c = KAT[cid]
+    if c["passes"]:
+        oracle.assert_evm(expand(c["act"]), expand(c["ref"]), c["evm_db"])
+    else:
+        with pytest.raises(AssertionError):
+            oracle.assert_evm(expand(c["act"]), expand(c["ref"]), c["evm_db"])
+    # the package's numpy restatement of the macro must agree with the C one
+    import aether_primitives_amd as ap
+    if c["passes"]:
+        ap.assert_evm(expand(c["act"]), expand(c["ref"]), c["evm_db"])
+    else:
+        with pytest.raises(AssertionError):
+            ap.assert_evm(expand(c["act"]), expand(c["ref"]), c["evm_db"])
+
+
+def test_assert_evm_rejects_nan_and_bad_args(oracle):
+    r = np.ones(2, np.complex64)
+    a = r.copy(); a[1] = np.nan
+    with pytest.raises(AssertionError): oracle.assert_evm(a, r)
+    with pytest.raises(AssertionError): oracle.assert_evm(r, r[:1])
+    with pytest.raises(AssertionError): oracle.assert_evm(r, r, 3.0)
+
+
+def test_qpsk_kat(oracle):
+    c = KAT["qpsk_table"]
+    assert bits_equal(oracle.qpsk_modulate(np.array(c["bits"], np.uint8)), expand(c["expect"]))
+    # demod quirk: second bit is emitted as idx & 2 (modulation.rs:54)
+    d = oracle.qpsk_demod_naive(expand(c["expect"]))
+    assert d.tolist() == [0, 0, 1, 0, 0, 2, 1, 2]
+
+
+def test_fir_ols_matches_direct_convolution(oracle):
+    h = oracle.synth_lowpass_taps(64, 0.25)
+    assert abs(h.sum() - 1) < 1e-6
+    x = oracle.synth_cnormal(815, 10000)
+    truth = oracle.fir_direct_f64(h, x)
+    for hop in (1985, 1984):
+        y = oracle.fir_ols_f32(h, x, 2048, hop)
+        assert oracle.evm_db(y, truth) < -120
+    # history = continuing a stream: filtering in two pieces equals filtering at once
+    y_all = oracle.fir_ols_f32(h, x, 2048, 1984)
+    y2 = oracle.fir_ols_f32(h, x[5000:], 2048, 1984, hist=x[5000 - 63:5000])
+    assert oracle.evm_db(y2, truth[5000:]) < -120
+    assert oracle.evm_db(y2, y_all[5000:]) < -120
+    assert bits_equal(oracle.fir_ols_f32(h, x, 2048, 1984, threads=3), y_all)
+
+
+def test_synth_is_deterministic(oracle):
+    a = oracle.synth_cnormal(815, 4096); b = oracle.synth_cnormal(815, 4096)
+    assert bits_equal(a, b) and not bits_equal(a, oracle.synth_cnormal(816, 4096))
+    p = float(np.mean(np.abs(a.astype(np.complex128)) ** 2))
+    assert 0.9 < p < 1.1
