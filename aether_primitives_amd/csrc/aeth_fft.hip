@@ -28,19 +28,20 @@ using namespace aeth::fftk;
 namespace {
 
 // =============================== stockham_pow2 ================================
-template <class C, bool SWAP>
+template <class C, int S>
 __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
-                                                          const cf *__restrict__ twN, size_t batch, float scale)
+                                                          const cf *__restrict__ twL, size_t batch, float scale)
 {
-    __shared__ cf lds_all[C::LDS_ELEMS];
-    const int tid = threadIdx.x % C::T;
-    const int fl = threadIdx.x / C::T;
+    __shared__ cf lds_all[C::LDS_TOTAL];
+    const int tid = (C::F == 1) ? (int)threadIdx.x : (int)(threadIdx.x % C::T);
+    const int fl = (C::F == 1) ? 0 : (int)(threadIdx.x / C::T);
     cf *lds = lds_all + fl * C::LDS_FRAME;
 
     cf tw[C::TW];
-    load_twiddles<C>(tw, twN, tid);
+    load_twiddles_lane<C>(tw, twL, tid);
 
     const size_t ngroups = (batch + C::F - 1) / C::F;
+    bool par = false;
     for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const size_t frame = g * C::F + fl;
         const bool active = frame < batch;
@@ -48,23 +49,21 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
         cf *dst = out + frame * C::N + tid;
         cf w[C::P];
 #pragma unroll
-        for (int m = 0; m < C::P; m++) {
-            cf v = active ? src[m * C::T] : mk(0.f, 0.f);
-            w[m] = SWAP ? cswap(v) : v;
-        }
-        fft_in_regs<C>(w, tw, lds, tid);
+        for (int m = 0; m < C::P; m++) w[m] = active ? src[m * C::T] : mk(0.f, 0.f);
+        // an odd number of exchanges per transform flips the image parity every frame
+        if (fft_next_par<C>(0) == 0 || !par) fft_in_regs<C, S, 0>(w, tw, lds, tid);
+        else fft_in_regs<C, S, 1>(w, tw, lds, tid);
+        par = (fft_next_par<C>(0) != 0) && !par;
         if (active) {
+            const cf ss = mk(scale, scale);
 #pragma unroll
-            for (int m = 0; m < C::P; m++) {
-                cf v = cscale(w[m], scale);
-                dst[m * C::T] = SWAP ? cswap(v) : v;
-            }
+            for (int m = 0; m < C::P; m++) dst[m * C::T] = cscale_k(w[m], ss);
         }
     }
 }
 
 template <class C>
-int launch_pow2(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
     const aeth_ctx *ctx = plan->ctx;
     size_t ngroups = (batch + C::F - 1) / C::F;
@@ -72,16 +71,35 @@ int launch_pow2(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int s
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
     if (sign > 0)
-        hipLaunchKernelGGL((fft_pow2_kernel<C, true>), dim3(grid), dim3(C::WG), 0, ctx->stream, in, out, plan->tw_dev, batch, scale);
+        hipLaunchKernelGGL((fft_pow2_kernel<C, +1>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
     else
-        hipLaunchKernelGGL((fft_pow2_kernel<C, false>), dim3(grid), dim3(C::WG), 0, ctx->stream, in, out, plan->tw_dev, batch, scale);
+        hipLaunchKernelGGL((fft_pow2_kernel<C, -1>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
 
-int dispatch_pow2(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+int dispatch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
 #define AETH_BODY(NN) return launch_pow2<typename CfgFor<NN>::type>(plan, in, out, batch, sign, scale)
+    AETH_POW2_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
+#undef AETH_BODY
+}
+
+template <class C>
+int build_lane_table(aeth_fft *plan)
+{
+    const size_t elems = (size_t)C::TW * C::T;
+    AETH_HIP(hipMalloc((void **)&plan->tw_lane_dev, elems * sizeof(float2)));
+    hipLaunchKernelGGL((build_lane_twiddles<C>), dim3(1), dim3(C::T < 64 ? 64 : C::T), 0, plan->ctx->stream,
+                       (const cf *)plan->tw_dev, (cf *)plan->tw_lane_dev);
+    AETH_HIP(hipGetLastError());
+    AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+    return AETH_OK;
+}
+
+int plan_pow2(aeth_fft *plan)
+{
+#define AETH_BODY(NN) return build_lane_table<typename CfgFor<NN>::type>(plan)
     AETH_POW2_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
 #undef AETH_BODY
 }
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
                 const int j = (i - k) * R + k;
                 auto ld = [&](int r) -> cf {
                     cf v = X[i + r * m];
-                    return (p > 1 && r > 0) ? cmul(v, twN[r * k * step]) : v;
+                    return (p > 1 && r > 0) ? cmul_plain(v, twN[r * k * step]) : v;
                 };
                 auto st = [&](int r, cf v) {
                     if (last) {
@@ -204,17 +222,17 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
                 };
                 if (R == 2) {
                     cf u[2] = {ld(0), ld(1)};
-                    Bfly<2>::run(u);
+                    Bfly<2, -1>::run(u);
                     st(0, u[0]); st(1, u[1]);
                 } else if (R == 4) {
                     cf u[4] = {ld(0), ld(1), ld(2), ld(3)};
-                    Bfly<4>::run(u);
+                    Bfly<4, -1>::run(u);
                     st(0, u[0]); st(1, u[1]); st(2, u[2]); st(3, u[3]);
                 } else if (R == 8) {
                     cf u[8];
 #pragma unroll
                     for (int r = 0; r < 8; r++) u[r] = ld(r);
-                    Bfly<8>::run(u);
+                    Bfly<8, -1>::run(u);
 #pragma unroll
                     for (int r = 0; r < 8; r++) st(r, u[r]);
                 } else if (R == 3) {
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
                     const int rstep = n / R;
                     for (int q = 0; q < R; q++) {
                         cf acc = ld(0);
-                        for (int r = 1; r < R; r++) acc = cadd(acc, cmul(ld(r), twN[((r * q) % R) * rstep]));
+                        for (int r = 1; r < R; r++) acc = cadd_plain(acc, cmul_plain(ld(r), twN[((r * q) % R) * rstep]));
                         st(q, acc);
                     }
                 }
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
     }
 }
 
-int launch_mixed(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
     const aeth_ctx *ctx = plan->ctx;
     MixedDesc d;
@@ -261,9 +279,9 @@ int launch_mixed(const aeth_fft *plan, const cf *in, cf *out, size_t batch, int 
     if (grid < 1) grid = 1;
     const size_t shmem = 2 * plan->len * sizeof(cf);
     if (sign > 0)
-        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, in, out, plan->tw_dev, d, batch, scale);
+        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale);
     else
-        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, in, out, plan->tw_dev, d, batch, scale);
+        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -283,15 +301,15 @@ bool factorize_mixed(size_t n, std::vector<int> &fac)
     return n == 1 && fac.size() <= (size_t)kMaxFactors;
 }
 
-int make_twiddles(aeth_ctx *ctx, size_t n, cf **out_dev)
+int make_twiddles(aeth_ctx *ctx, size_t n, float2 **out_dev)
 {
-    std::vector<cf> h(n ? n : 1);
+    std::vector<float2> h(n ? n : 1);
     for (size_t k = 0; k < n; k++) {
         double a = -2.0 * M_PI * (double)k / (double)n;
         h[k] = make_float2((float)cos(a), (float)sin(a));
     }
-    AETH_HIP(hipMalloc((void **)out_dev, h.size() * sizeof(cf)));
-    AETH_HIP(hipMemcpyAsync(*out_dev, h.data(), h.size() * sizeof(cf), hipMemcpyHostToDevice, ctx->stream));
+    AETH_HIP(hipMalloc((void **)out_dev, h.size() * sizeof(float2)));
+    AETH_HIP(hipMemcpyAsync(*out_dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     AETH_HIP(hipStreamSynchronize(ctx->stream));
     return AETH_OK;
 }
@@ -309,13 +327,13 @@ int fft_ensure_tmp(aeth_fft *plan, size_t elems)
         plan->tmp_dev = nullptr;
         plan->tmp_elems = 0;
     }
-    AETH_HIP(hipMalloc((void **)&plan->tmp_dev, elems * sizeof(cf)));
+    AETH_HIP(hipMalloc((void **)&plan->tmp_dev, elems * sizeof(float2)));
     plan->tmp_elems = elems;
     return AETH_OK;
 }
 
 // device-pointer transform of `batch` frames; in may equal out
-int fft_run(aeth_fft *plan, const cf *in, cf *out, size_t batch, int sign, float scale)
+int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
     if (batch == 0 || plan->len == 0) return AETH_OK;
     switch (plan->algo) {
@@ -364,9 +382,10 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
         rc = aeth::fft_plan_bluestein(p);
     }
     if (rc == AETH_OK) rc = make_twiddles(ctx, len, &p->tw_dev);
+    if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_POW2) rc = plan_pow2(p);
     if (rc == AETH_OK) rc = aeth::fft_ensure_tmp(p, 2 * len * max_batch);
     if (rc == AETH_OK) {
-        hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * len * sizeof(cf), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * len * sizeof(float2), hipHostMallocDefault);
         if (e != hipSuccess) rc = aeth::hip_fail(e, "hipHostMalloc");
     }
     if (rc != AETH_OK) { aeth_fft_destroy(p); return rc; }
@@ -381,6 +400,7 @@ int aeth_fft_destroy(aeth_fft *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     aeth::fft_plan_release_children(p);
     if (p->tw_dev) (void)hipFree(p->tw_dev);
+    if (p->tw_lane_dev) (void)hipFree(p->tw_lane_dev);
     if (p->tmp_dev) (void)hipFree(p->tmp_dev);
     if (p->tmp_host) (void)hipHostFree(p->tmp_host);
     delete p;
@@ -407,7 +427,7 @@ int aeth_fft_exec(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out,
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out), AETH_E_ALIGN, "pointer not 8-byte aligned");
     const float s = aeth_scale_factor(kind, p->len, x);                     /* fft.rs:22-37, n = frame length */
-    return aeth::fft_run(p, (const cf *)in, (cf *)out, batch, sign, s);
+    return aeth::fft_run(p, (const float2 *)in, (float2 *)out, batch, sign, s);
 }
 
 int aeth_fft_exec_tmp(aeth_fft *p, const aeth_cf32 *in, size_t n_in, size_t batch, int sign, int kind, float x,
@@ -420,9 +440,9 @@ int aeth_fft_exec_tmp(aeth_fft *p, const aeth_cf32 *in, size_t n_in, size_t batc
     if (batch == 0) return AETH_OK;
     AETH_REQUIRE(in, AETH_E_ARG, "null pointer");
     rc = aeth::fft_ensure_tmp(p, 2 * n_in); if (rc) return rc;
-    cf *dst = p->tmp_dev + n_in;                                            /* tmp[len..], fft.rs:213 */
+    float2 *dst = p->tmp_dev + n_in;                                            /* tmp[len..], fft.rs:213 */
     const float s = aeth_scale_factor(kind, p->len, x);
-    rc = aeth::fft_run(p, (const cf *)in, dst, batch, sign, s); if (rc) return rc;
+    rc = aeth::fft_run(p, (const float2 *)in, dst, batch, sign, s); if (rc) return rc;
     *view = (const aeth_cf32 *)dst;
     return AETH_OK;
 }
@@ -435,7 +455,7 @@ int aeth_fft_exec_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 
     AETH_REQUIRE(n_out == p->len, AETH_E_LEN, "Output and FFT must be the same length");
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
     hipStream_t st = p->ctx->stream;
-    const size_t bytes = p->len * sizeof(cf);
+    const size_t bytes = p->len * sizeof(float2);
     AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));   /* tmp[..len] <- input, fft.rs:168 */
     const float s = aeth_scale_factor(kind, p->len, x);
     rc = aeth::fft_run(p, p->tmp_dev, p->tmp_dev + p->len, 1, sign, s); if (rc) return rc;
@@ -453,7 +473,7 @@ int aeth_fft_exec_tmp_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, int si
     AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
     AETH_REQUIRE(in, AETH_E_ARG, "null pointer");
     hipStream_t st = p->ctx->stream;
-    const size_t bytes = p->len * sizeof(cf);
+    const size_t bytes = p->len * sizeof(float2);
     AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));
     const float s = aeth_scale_factor(kind, p->len, x);
     rc = aeth::fft_run(p, p->tmp_dev, p->tmp_dev + p->len, 1, sign, s); if (rc) return rc;

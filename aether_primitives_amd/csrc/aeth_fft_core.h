@@ -14,63 +14,210 @@
 //   leaves its results in the w[] slots of the natural-order output, ready for a
 //   coalesced store -- or for the first pass of the next transform (FIR) with no
 //   exchange in between.
-// Only the -j exponent is coded.  The +j transform (the reference's `fwd`,
-// src/fft.rs:148) swaps re/im on load and on store: swap(DFT-(swap x)) = DFT+(x),
-// which is a register renaming at compile time.
+//
+// Arithmetic: a cf32 sample is one 64-bit VGPR pair and every complex operation is
+// one or two packed-f32 VALU instructions (v_pk_add/mul/fma_f32).  The op_sel /
+// neg_lo / neg_hi operand modifiers do the re<->im swaps and sign flips that
+// multiplication by +-j, conjugation and the complex product need, so there are no
+// v_mov shuffles; hipcc does not select those modifiers from C++, hence the
+// one-instruction inline-asm primitives below (plain VALU: no hazards or waitcnts of
+// their own, freely scheduled by the compiler).
+//
+// Direction is a template parameter S (sign of the exponent).  Tables always hold
+// exp(-2 pi i k / N); S = +1 multiplies by the conjugate and flips the +-j rotations
+// at compile time.  The reference's `fwd` is S = +1 (src/fft.rs:148 plans it with
+// rustfft's inverse = true), `bwd` is S = -1.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
+#ifndef AETH_LDS_DB_LIMIT
+#define AETH_LDS_DB_LIMIT (48 * 1024)   /* two exchange images per workgroup up to this many bytes */
+#endif
+
 namespace aeth {
 namespace fftk {
 
-using cf = float2;
+typedef float cf __attribute__((ext_vector_type(2)));   // (re, im): one 64-bit register pair
 
-__device__ __forceinline__ cf mk(float a, float b) { return make_float2(a, b); }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf w) { return mk(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
-__device__ __forceinline__ cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
-__device__ __forceinline__ cf mul_mj(cf a) { return mk(a.y, -a.x); }   // a * (-j)
+__device__ __forceinline__ cf mk(float a, float b) { cf r = {a, b}; return r; }
+
+// ---- one-instruction packed primitives ------------------------------------------
+__device__ __forceinline__ cf cadd(cf a, cf b)
+{
+    cf d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+__device__ __forceinline__ cf csub(cf a, cf b)
+{
+    cf d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// a + (-j) b = (a.re + b.im, a.im - b.re)
+__device__ __forceinline__ cf cadd_mjb(cf a, cf b)
+{
+    cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a + (+j) b = (a.re - b.im, a.im + b.re)
+__device__ __forceinline__ cf cadd_pjb(cf a, cf b)
+{
+    cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a + rot*b and a - rot*b with rot = exp(S*j*pi/2) = S*j
+template <int S> __device__ __forceinline__ cf cadd_rot(cf a, cf b) { return S < 0 ? cadd_mjb(a, b) : cadd_pjb(a, b); }
+template <int S> __device__ __forceinline__ cf csub_rot(cf a, cf b) { return S < 0 ? cadd_pjb(a, b) : cadd_mjb(a, b); }
+
+// Dependent instruction pairs are kept inside ONE asm statement: hipcc pads an s_nop
+// between two asm statements when the second reads what the first wrote (it cannot see
+// that v_pk_*_f32 has no dst-select forwarding hazard); inside a statement the hardware's
+// own VALU interlock is all that is needed.
+#define AETH_CMUL_MUL  " op_sel:[0,0] op_sel_hi:[0,1]"
+#define AETH_CMUL_FMA  " op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[0,0,0]"
+#define AETH_CMULC_MUL " op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]"
+#define AETH_CMULC_FMA " op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+
+// a * w (w in VGPRs)
+__device__ __forceinline__ cf cmul(cf a, cf w)
+{
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2" AETH_CMUL_MUL "\n\tv_pk_fma_f32 %0, %1, %2, %0" AETH_CMUL_FMA
+        : "=&v"(d) : "v"(a), "v"(w));
+    return d;
+}
+// a * conj(w)
+__device__ __forceinline__ cf cmul_conj(cf a, cf w)
+{
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2" AETH_CMULC_MUL "\n\tv_pk_fma_f32 %0, %1, %2, %0" AETH_CMULC_FMA
+        : "=&v"(d) : "v"(a), "v"(w));
+    return d;
+}
+// a * (S < 0 ? w : conj(w)) : twiddle for exponent sign S from a table of exp(-j...)
+template <int S> __device__ __forceinline__ cf ctw(cf a, cf w) { return S < 0 ? cmul(a, w) : cmul_conj(a, w); }
+
+// the same with a wave-uniform constant held in an SGPR pair
+__device__ __forceinline__ cf cmul_k(cf a, cf w)
+{
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2" AETH_CMUL_MUL "\n\tv_pk_fma_f32 %0, %1, %2, %0" AETH_CMUL_FMA
+        : "=&v"(d) : "v"(a), "s"(w));
+    return d;
+}
+__device__ __forceinline__ cf cmul_conj_k(cf a, cf w)
+{
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2" AETH_CMULC_MUL "\n\tv_pk_fma_f32 %0, %1, %2, %0" AETH_CMULC_FMA
+        : "=&v"(d) : "v"(a), "s"(w));
+    return d;
+}
+template <int S> __device__ __forceinline__ cf ctw_k(cf a, cf w) { return S < 0 ? cmul_k(a, w) : cmul_conj_k(a, w); }
+
+// a * s, s real and wave-uniform; ss = (s, s)
+__device__ __forceinline__ cf cscale_k(cf a, cf ss)
+{
+    cf d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(ss)); return d;
+}
+
+// rotations by odd multiples of pi/4, as "x +- (+-j) x" sums:
+//   R1(a) = sqrt2 * a * exp(S*j*pi/4)    S=-1: a(1-j) = (re+im, im-re);   S=+1: a(1+j) = (re-im, im+re)
+//   R3(a) = sqrt2 * a * exp(S*j*3pi/4)   S=-1: a(-1-j) = (im-re, -re-im); S=+1: a(-1+j) = (-re-im, re-im)
+#define AETH_R1_M " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]"
+#define AETH_R1_P " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"
+#define AETH_R3_M " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]"
+#define AETH_R3_P " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]"
+
+// a * W8^K for exponent sign S (K = 1 or 3): rotate, then scale by 1/sqrt2 (hh = (sqrt.5, sqrt.5))
+template <int S, int K> __device__ __forceinline__ cf cmul_w8(cf a, cf hh)
+{
+    cf d;
+    if constexpr (K == 1 && S < 0) asm("v_pk_add_f32 %0, %1, %1" AETH_R1_M "\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(d) : "v"(a), "s"(hh));
+    if constexpr (K == 1 && S > 0) asm("v_pk_add_f32 %0, %1, %1" AETH_R1_P "\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(d) : "v"(a), "s"(hh));
+    if constexpr (K == 3 && S < 0) asm("v_pk_add_f32 %0, %1, %1" AETH_R3_M "\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(d) : "v"(a), "s"(hh));
+    if constexpr (K == 3 && S > 0) asm("v_pk_add_f32 %0, %1, %1" AETH_R3_P "\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(d) : "v"(a), "s"(hh));
+    return d;
+}
+// (e + W8^K o, e - W8^K o): rotate o, then two fused multiply-adds by +-1/sqrt2
+template <int S, int K> __device__ __forceinline__ void bfly_w8(cf e, cf o, cf hh, cf &plus, cf &minus)
+{
+    cf r;
+#define AETH_W8_TAIL "\n\tv_pk_fma_f32 %0, %2, %5, %4\n\tv_pk_fma_f32 %1, %2, %5, %4 neg_lo:[1,0,0] neg_hi:[1,0,0]"
+    if constexpr (K == 1 && S < 0) asm("v_pk_add_f32 %2, %3, %3" AETH_R1_M AETH_W8_TAIL : "=&v"(plus), "=&v"(minus), "=&v"(r) : "v"(o), "v"(e), "s"(hh));
+    if constexpr (K == 1 && S > 0) asm("v_pk_add_f32 %2, %3, %3" AETH_R1_P AETH_W8_TAIL : "=&v"(plus), "=&v"(minus), "=&v"(r) : "v"(o), "v"(e), "s"(hh));
+    if constexpr (K == 3 && S < 0) asm("v_pk_add_f32 %2, %3, %3" AETH_R3_M AETH_W8_TAIL : "=&v"(plus), "=&v"(minus), "=&v"(r) : "v"(o), "v"(e), "s"(hh));
+    if constexpr (K == 3 && S > 0) asm("v_pk_add_f32 %2, %3, %3" AETH_R3_P AETH_W8_TAIL : "=&v"(plus), "=&v"(minus), "=&v"(r) : "v"(o), "v"(e), "s"(hh));
+#undef AETH_W8_TAIL
+}
+
+// ---- plain C++ helpers (generic kernels, not on the hot path) ---------------------
 __device__ __forceinline__ cf cswap(cf a) { return mk(a.y, a.x); }
+__device__ __forceinline__ cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+__device__ __forceinline__ cf mul_mj(cf a) { return mk(a.y, -a.x); }
+__device__ __forceinline__ cf cmul_plain(cf a, cf w) { return mk(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+__device__ __forceinline__ cf cadd_plain(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub_plain(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
 
 constexpr float kSqrtHalf = 0.70710678118654752440f;
 constexpr float kCosPi8 = 0.92387953251128675613f;
 constexpr float kSinPi8 = 0.38268343236508977173f;
 
-// a * W8^1 = a * (1 - j)/sqrt2 ; a * W8^3 = a * (-1 - j)/sqrt2
-__device__ __forceinline__ cf mul_w8_1(cf a) { return mk((a.x + a.y) * kSqrtHalf, (a.y - a.x) * kSqrtHalf); }
-__device__ __forceinline__ cf mul_w8_3(cf a) { return mk((a.y - a.x) * kSqrtHalf, -(a.x + a.y) * kSqrtHalf); }
-
-// a * W16^M, W16 = exp(-2 pi i / 16)
-template <int M>
-__device__ __forceinline__ cf mul_w16(cf a)
+// 4-point DFT in place on (a, b, c, d) -> (y0, y1, y2, y3), exponent sign S.
+//   y1 = (a-c) + rot (b-d),  y3 = (a-c) - rot (b-d),  rot = S*j
+// One asm statement of 8 packed instructions: hipcc pads a wait state after every asm
+// statement whose result the next instruction may read, so grouping the butterfly keeps
+// those s_nop's out of the inner sequence.  CROT: input c stands for rot*c (the free
+// W16^4 twiddle inside radix 16).
+#define AETH_MJ " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]"   /* x + (-j) y */
+#define AETH_PJ " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"   /* x + (+j) y */
+#define AETH_NEG " neg_lo:[0,1] neg_hi:[0,1]"                               /* x - y      */
+template <int S, bool CROT>
+__device__ __forceinline__ void dft4_inplace(cf &a, cf &b, cf &c, cf &d)
 {
-    if constexpr (M == 0) return a;
-    else if constexpr (M == 1) return cmul(a, mk(kCosPi8, -kSinPi8));
-    else if constexpr (M == 2) return mul_w8_1(a);
-    else if constexpr (M == 3) return cmul(a, mk(kSinPi8, -kCosPi8));
-    else if constexpr (M == 4) return mul_mj(a);
-    else if constexpr (M == 6) return mul_w8_3(a);
-    else if constexpr (M == 9) return cmul(a, mk(-kCosPi8, kSinPi8));
-    else { static_assert(M < 0, "unsupported W16 power"); return a; }
+    cf t0, t1, t2, t3;
+    if constexpr (S < 0 && !CROT)
+        asm("v_pk_add_f32 %4, %0, %2\n\tv_pk_add_f32 %5, %0, %2" AETH_NEG "\n\t"
+            "v_pk_add_f32 %6, %1, %3\n\tv_pk_add_f32 %7, %1, %3" AETH_NEG "\n\t"
+            "v_pk_add_f32 %0, %4, %6\n\tv_pk_add_f32 %2, %4, %6" AETH_NEG "\n\t"
+            "v_pk_add_f32 %1, %5, %7" AETH_MJ "\n\tv_pk_add_f32 %3, %5, %7" AETH_PJ
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    else if constexpr (S > 0 && !CROT)
+        asm("v_pk_add_f32 %4, %0, %2\n\tv_pk_add_f32 %5, %0, %2" AETH_NEG "\n\t"
+            "v_pk_add_f32 %6, %1, %3\n\tv_pk_add_f32 %7, %1, %3" AETH_NEG "\n\t"
+            "v_pk_add_f32 %0, %4, %6\n\tv_pk_add_f32 %2, %4, %6" AETH_NEG "\n\t"
+            "v_pk_add_f32 %1, %5, %7" AETH_PJ "\n\tv_pk_add_f32 %3, %5, %7" AETH_MJ
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    else if constexpr (S < 0 && CROT)
+        asm("v_pk_add_f32 %4, %0, %2" AETH_MJ "\n\tv_pk_add_f32 %5, %0, %2" AETH_PJ "\n\t"
+            "v_pk_add_f32 %6, %1, %3\n\tv_pk_add_f32 %7, %1, %3" AETH_NEG "\n\t"
+            "v_pk_add_f32 %0, %4, %6\n\tv_pk_add_f32 %2, %4, %6" AETH_NEG "\n\t"
+            "v_pk_add_f32 %1, %5, %7" AETH_MJ "\n\tv_pk_add_f32 %3, %5, %7" AETH_PJ
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    else
+        asm("v_pk_add_f32 %4, %0, %2" AETH_PJ "\n\tv_pk_add_f32 %5, %0, %2" AETH_MJ "\n\t"
+            "v_pk_add_f32 %6, %1, %3\n\tv_pk_add_f32 %7, %1, %3" AETH_NEG "\n\t"
+            "v_pk_add_f32 %0, %4, %6\n\tv_pk_add_f32 %2, %4, %6" AETH_NEG "\n\t"
+            "v_pk_add_f32 %1, %5, %7" AETH_PJ "\n\tv_pk_add_f32 %3, %5, %7" AETH_MJ
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
 }
 
+template <int S>
 __device__ __forceinline__ void dft4(cf a, cf b, cf c, cf d, cf &y0, cf &y1, cf &y2, cf &y3)
 {
-    cf s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = mul_mj(csub(b, d));
-    y0 = cadd(s0, s2);
-    y2 = csub(s0, s2);
-    y1 = cadd(s1, s3);
-    y3 = csub(s1, s3);
+    dft4_inplace<S, false>(a, b, c, d);
+    y0 = a; y1 = b; y2 = c; y3 = d;
+}
+template <int S>
+__device__ __forceinline__ void dft4_crot(cf a, cf b, cf c, cf d, cf &y0, cf &y1, cf &y2, cf &y3)
+{
+    dft4_inplace<S, true>(a, b, c, d);
+    y0 = a; y1 = b; y2 = c; y3 = d;
 }
 
-// in-register radix-R DFT, natural-order in, natural-order out
-template <int R> struct Bfly;
+// in-register radix-R DFT, natural-order in, natural-order out, exponent sign S
+template <int R, int S> struct Bfly;
 
-template <> struct Bfly<1> { static __device__ __forceinline__ void run(cf (&)[1]) {} };
+template <int S> struct Bfly<1, S> { static __device__ __forceinline__ void run(cf (&)[1]) {} };
 
-template <> struct Bfly<2> {
+template <int S> struct Bfly<2, S> {
     static __device__ __forceinline__ void run(cf (&u)[2])
     {
         cf a = u[0], b = u[1];
@@ -79,41 +226,50 @@ template <> struct Bfly<2> {
     }
 };
 
-template <> struct Bfly<4> {
-    static __device__ __forceinline__ void run(cf (&u)[4]) { dft4(u[0], u[1], u[2], u[3], u[0], u[1], u[2], u[3]); }
+template <int S> struct Bfly<4, S> {
+    static __device__ __forceinline__ void run(cf (&u)[4]) { dft4<S>(u[0], u[1], u[2], u[3], u[0], u[1], u[2], u[3]); }
 };
 
-template <> struct Bfly<8> {
+template <int S> struct Bfly<8, S> {
     static __device__ __forceinline__ void run(cf (&u)[8])
     {
-        cf e0, e1, e2, e3, o0, o1, o2, o3;
-        dft4(u[0], u[2], u[4], u[6], e0, e1, e2, e3);
-        dft4(u[1], u[3], u[5], u[7], o0, o1, o2, o3);
-        o1 = mul_w8_1(o1);
-        o2 = mul_mj(o2);
-        o3 = mul_w8_3(o3);
-        u[0] = cadd(e0, o0); u[4] = csub(e0, o0);
-        u[1] = cadd(e1, o1); u[5] = csub(e1, o1);
-        u[2] = cadd(e2, o2); u[6] = csub(e2, o2);
-        u[3] = cadd(e3, o3); u[7] = csub(e3, o3);
+        const cf hh = mk(kSqrtHalf, kSqrtHalf);
+        cf e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
+        dft4_inplace<S, false>(e0, e1, e2, e3);
+        dft4_inplace<S, false>(o0, o1, o2, o3);
+        u[0] = cadd(e0, o0);        u[4] = csub(e0, o0);
+        bfly_w8<S, 1>(e1, o1, hh, u[1], u[5]);
+        u[2] = cadd_rot<S>(e2, o2); u[6] = csub_rot<S>(e2, o2);
+        bfly_w8<S, 3>(e3, o3, hh, u[3], u[7]);
     }
 };
 
-template <> struct Bfly<16> {
+template <int S> struct Bfly<16, S> {
     static __device__ __forceinline__ void run(cf (&u)[16])
     {
-        cf t0[4], t1[4], t2[4], t3[4];
-        dft4(u[0], u[4], u[8],  u[12], t0[0], t0[1], t0[2], t0[3]);
-        dft4(u[1], u[5], u[9],  u[13], t1[0], t1[1], t1[2], t1[3]);
-        dft4(u[2], u[6], u[10], u[14], t2[0], t2[1], t2[2], t2[3]);
-        dft4(u[3], u[7], u[11], u[15], t3[0], t3[1], t3[2], t3[3]);
-        t1[1] = mul_w16<1>(t1[1]); t1[2] = mul_w16<2>(t1[2]); t1[3] = mul_w16<3>(t1[3]);
-        t2[1] = mul_w16<2>(t2[1]); t2[2] = mul_w16<4>(t2[2]); t2[3] = mul_w16<6>(t2[3]);
-        t3[1] = mul_w16<3>(t3[1]); t3[2] = mul_w16<6>(t3[2]); t3[3] = mul_w16<9>(t3[3]);
-        dft4(t0[0], t1[0], t2[0], t3[0], u[0], u[4], u[8],  u[12]);
-        dft4(t0[1], t1[1], t2[1], t3[1], u[1], u[5], u[9],  u[13]);
-        dft4(t0[2], t1[2], t2[2], t3[2], u[2], u[6], u[10], u[14]);
-        dft4(t0[3], t1[3], t2[3], t3[3], u[3], u[7], u[11], u[15]);
+        const cf hh = mk(kSqrtHalf, kSqrtHalf);
+        const cf w1 = mk(kCosPi8, -kSinPi8), w3 = mk(kSinPi8, -kCosPi8), w9 = mk(-kCosPi8, kSinPi8);
+        // rows: 4-point DFTs over p of x[q + 4p]; t_q[kp] lands in u[q + 4 kp]
+        dft4_inplace<S, false>(u[0], u[4], u[8],  u[12]);
+        dft4_inplace<S, false>(u[1], u[5], u[9],  u[13]);
+        dft4_inplace<S, false>(u[2], u[6], u[10], u[14]);
+        dft4_inplace<S, false>(u[3], u[7], u[11], u[15]);
+        // column kp: z[q] = t_q[kp] * W16^(q*kp), then a 4-point DFT over q -> X[kp + 4 kq]
+        cf c0[4] = {u[0], u[1], u[2], u[3]};
+        cf c1[4] = {u[4], ctw_k<S>(u[5], w1), cmul_w8<S, 1>(u[6], hh), ctw_k<S>(u[7], w3)};          // W16^1,2,3
+        cf c2[4] = {u[8], cmul_w8<S, 1>(u[9], hh), u[10], cmul_w8<S, 3>(u[11], hh)};               // W16^2,(4),6
+        cf c3[4] = {u[12], ctw_k<S>(u[13], w3), cmul_w8<S, 3>(u[14], hh), ctw_k<S>(u[15], w9)};     // W16^3,6,9
+        dft4_inplace<S, false>(c0[0], c0[1], c0[2], c0[3]);
+        dft4_inplace<S, false>(c1[0], c1[1], c1[2], c1[3]);
+        dft4_inplace<S, true>(c2[0], c2[1], c2[2], c2[3]);      // W16^4 = rot, folded into the adds
+        dft4_inplace<S, false>(c3[0], c3[1], c3[2], c3[3]);
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) {
+            u[0 + 4 * kq] = c0[kq];
+            u[1 + 4 * kq] = c1[kq];
+            u[2 + 4 * kq] = c2[kq];
+            u[3 + 4 * kq] = c3[kq];
+        }
     }
 };
 
@@ -145,7 +301,9 @@ struct Cfg {
     // LDS image of one frame: one pad slot per 16 elements (kills the 16-way write
     // conflict of the first exchange, whose lanes write at stride 16 elements)
     static constexpr int LDS_FRAME = (NPASS > 1) ? (N_ + N_ / 16) : 0;
-    static constexpr int LDS_ELEMS = (LDS_FRAME * F > 0) ? LDS_FRAME * F : 1;
+    static constexpr int LDS_ELEMS = (LDS_FRAME * F > 0) ? LDS_FRAME * F : 1;   // one image of the workgroup's frames
+    static constexpr bool DB = (NPASS > 1) && (2 * LDS_ELEMS * 8 <= AETH_LDS_DB_LIMIT);   // room for two images
+    static constexpr int LDS_TOTAL = DB ? 2 * LDS_ELEMS : LDS_ELEMS;
     static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
     static_assert(N_ % P_ == 0 && P_ % R0_ == 0 && P_ % R1_ == 0 && P_ % R2_ == 0 && P_ % R3_ == 0, "bad P");
     static_assert(WG % T == 0, "frames must tile the workgroup");
@@ -154,16 +312,16 @@ struct Cfg {
 __device__ __forceinline__ int lidx(int e) { return e + (e >> 4); }
 
 // twN: master table exp(-2 pi i k / N), k in [0, N)
-template <class C, int S>
+template <class C, int PASS>
 __device__ __forceinline__ void load_tw_pass(cf (&tw)[C::TW], const cf *__restrict__ twN, int tid)
 {
-    constexpr int R = C::radix(S), B = C::P / R, p = C::pbefore(S);
+    constexpr int R = C::radix(PASS), B = C::P / R, p = C::pbefore(PASS);
     constexpr int step = C::N / (p * R);
 #pragma unroll
     for (int b = 0; b < B; b++) {
         const int k = (tid + b * C::T) & (p - 1);
 #pragma unroll
-        for (int r = 1; r < R; r++) tw[C::twoff(S) + b * (R - 1) + (r - 1)] = twN[r * k * step];
+        for (int r = 1; r < R; r++) tw[C::twoff(PASS) + b * (R - 1) + (r - 1)] = twN[r * k * step];
     }
 }
 
@@ -175,12 +333,46 @@ __device__ __forceinline__ void load_twiddles(cf (&tw)[C::TW], const cf *__restr
     if constexpr (C::NPASS > 3) load_tw_pass<C, 3>(tw, twN, tid);
 }
 
-template <class C, int S>
+// The same registers from the plan's per-lane table twL[slot * T + tid] (built once per
+// plan by build_lane_twiddles): one coalesced 8-byte load per slot instead of a 64-way
+// gather from the master table, which matters because every launch pays this prologue.
+template <class C>
+__device__ __forceinline__ void load_twiddles_lane(cf (&tw)[C::TW], const cf *__restrict__ twL, int tid)
+{
+    if constexpr (C::NPASS > 1) {
+#pragma unroll
+        for (int s = 0; s < C::TW; s++) tw[s] = twL[s * C::T + tid];
+    }
+}
+
+template <class C>
+__global__ void build_lane_twiddles(const cf *__restrict__ twN, cf *__restrict__ twL)
+{
+    const int tid = threadIdx.x;
+    if (tid >= C::T) return;
+    cf tw[C::TW];
+    load_twiddles<C>(tw, twN, tid);
+    if constexpr (C::NPASS > 1) {
+#pragma unroll
+        for (int s = 0; s < C::TW; s++) twL[s * C::T + tid] = tw[s];
+    }
+}
+
+// Exchange buffers: where two LDS images of the frame fit (C::DB) consecutive exchanges
+// ping-pong between them, which needs ONE barrier per exchange (write k -> barrier ->
+// read k; image k is next written only after the barrier of exchange k+1, which every
+// lane passes after it has finished reading image k).  With a single image a second
+// barrier in front of the writes keeps late readers safe.
+template <class C, int PASS, int S, int PAR>
 __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], cf *__restrict__ lds, int tid)
 {
-    constexpr int R = C::radix(S), B = C::P / R, p = C::pbefore(S);
-    constexpr bool last = (S == C::NPASS - 1);
-    if constexpr (!last) __syncthreads();   // earlier readers of this LDS image are done
+    constexpr int R = C::radix(PASS), B = C::P / R, p = C::pbefore(PASS);
+    constexpr bool last = (PASS == C::NPASS - 1);
+    cf *img = lds;
+    if constexpr (!last) {
+        if constexpr (C::DB) img = lds + (((PAR + PASS) & 1) ? C::LDS_ELEMS : 0);
+        else __syncthreads();               // earlier readers of the single image are done
+    }
 #pragma unroll
     for (int b = 0; b < B; b++) {
         cf u[R];
@@ -188,9 +380,9 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
         for (int r = 0; r < R; r++) u[r] = w[b + r * B];
         if constexpr (p > 1) {
 #pragma unroll
-            for (int r = 1; r < R; r++) u[r] = cmul(u[r], tw[C::twoff(S) + b * (R - 1) + (r - 1)]);
+            for (int r = 1; r < R; r++) u[r] = ctw<S>(u[r], tw[C::twoff(PASS) + b * (R - 1) + (r - 1)]);
         }
-        Bfly<R>::run(u);
+        Bfly<R, S>::run(u);
         if constexpr (last) {
 #pragma unroll
             for (int r = 0; r < R; r++) w[b + r * B] = u[r];
@@ -199,25 +391,28 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
             const int k = i & (p - 1);
             const int j = (i - k) * R + k;
 #pragma unroll
-            for (int r = 0; r < R; r++) lds[lidx(j + r * p)] = u[r];
+            for (int r = 0; r < R; r++) img[lidx(j + r * p)] = u[r];
         }
     }
     if constexpr (!last) {
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < C::P; m++) w[m] = lds[lidx(tid + m * C::T)];
+        for (int m = 0; m < C::P; m++) w[m] = img[lidx(tid + m * C::T)];
     }
 }
 
-// full transform of the frame held in w[] (slot m = element tid + m*T), -j exponent
-template <class C>
+// full transform of the frame held in w[] (slot m = element tid + m*T), exponent sign S.
+// PAR = parity of the number of exchanges done so far on this LDS allocation (C::DB only);
+// the caller keeps it consistent (see fft_next_par).
+template <class C, int S, int PAR = 0>
 __device__ __forceinline__ void fft_in_regs(cf (&w)[C::P], const cf (&tw)[C::TW], cf *__restrict__ lds, int tid)
 {
-    run_pass<C, 0>(w, tw, lds, tid);
-    if constexpr (C::NPASS > 1) run_pass<C, 1>(w, tw, lds, tid);
-    if constexpr (C::NPASS > 2) run_pass<C, 2>(w, tw, lds, tid);
-    if constexpr (C::NPASS > 3) run_pass<C, 3>(w, tw, lds, tid);
+    run_pass<C, 0, S, PAR>(w, tw, lds, tid);
+    if constexpr (C::NPASS > 1) run_pass<C, 1, S, PAR>(w, tw, lds, tid);
+    if constexpr (C::NPASS > 2) run_pass<C, 2, S, PAR>(w, tw, lds, tid);
+    if constexpr (C::NPASS > 3) run_pass<C, 3, S, PAR>(w, tw, lds, tid);
 }
+template <class C> constexpr int fft_next_par(int par) { return (par + C::NPASS - 1) & 1; }
 
 // ---- the size table: one tuned decomposition per power of two ------------------
 template <int N> struct CfgFor;

@@ -22,6 +22,7 @@
 #include "aeth_fft_core.h"
 #include "aeth_fft_plan.h"
 
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -42,82 +43,155 @@ struct FmiArgs {
     const cf *hist;       // ntaps-1 samples preceding in[0], or null
     const cf *Hf;         // N spectrum multipliers, natural order
     const cf *twN;
+    const cf *twL;        // per-lane twiddle table of the plan (null: gather from twN)
     long long n;          // samples in `in` / outputs wanted
     long long nblocks;
     int hop, ov, nhist;
     float s_fwd, s_bwd;
+    int dbg;              // tuning only (AETH_FIR_DBG): 1 = skip prefetch loads, 2 = skip stores
 };
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf as_cf(u32x2 v) { return __builtin_bit_cast(cf, v); }
+__device__ __forceinline__ u32x2 as_u32x2(cf v) { return __builtin_bit_cast(u32x2, v); }
+
+// one block's input window -> registers (slot m = window element tid + m*T)
 template <class C>
-__global__ __launch_bounds__(C::WG) void fmi_kernel(FmiArgs a)
+__device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
 {
-    __shared__ cf lds_all[C::LDS_ELEMS];
-    const int tid = threadIdx.x % C::T;
-    const int fl = threadIdx.x / C::T;
-    cf *lds = lds_all + fl * C::LDS_FRAME;
-
-    cf tw[C::TW];
-    load_twiddles<C>(tw, a.twN, tid);
-    cf H[C::P];
+    const long long win0 = blk * a.hop - a.ov;              // first input sample of the window
+    if (blk >= a.nblocks) {
 #pragma unroll
-    for (int m = 0; m < C::P; m++) H[m] = a.Hf[tid + m * C::T];
-
-    const long long ngroups = (a.nblocks + C::F - 1) / C::F;
-    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const long long blk = g * C::F + fl;
-        const bool active = blk < a.nblocks;
-        const long long win0 = blk * a.hop - a.ov;          // first input sample of the window
-        cf w[C::P];
-        if (active && win0 >= 0 && win0 + C::N <= a.n) {
-            const cf *src = a.in + win0 + tid;
+        for (int m = 0; m < C::P; m++) x[m] = mk(0.f, 0.f);
+        return;
+    }
+    if constexpr (C::F == 1) {
+        if (win0 >= 0) {
+            // wave-uniform window: buffer loads, the descriptor's range check zero-fills past the end
+            long long left = a.n - win0;
+            int bytes = (int)(left < C::N ? left : C::N) * 8;
+            auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
-            for (int m = 0; m < C::P; m++) w[m] = cswap(src[m * C::T]);     // fwd = +j exponent
-        } else {
-#pragma unroll
-            for (int m = 0; m < C::P; m++) {
-                const long long gi = win0 + tid + m * C::T;
-                cf v = mk(0.f, 0.f);
-                if (active) {
-                    if (gi >= 0) { if (gi < a.n) v = a.in[gi]; }
-                    else if (a.hist && gi >= -(long long)a.nhist) v = a.hist[a.nhist + gi];
-                }
-                w[m] = cswap(v);
-            }
+            for (int m = 0; m < C::P; m++)
+                x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 0));
+            return;
         }
-        fft_in_regs<C>(w, tw, lds, tid);
+    }
+#pragma unroll
+    for (int m = 0; m < C::P; m++) {
+        const long long gi = win0 + tid + m * C::T;
+        cf v = mk(0.f, 0.f);
+        if (gi >= 0) { if (gi < a.n) v = a.in[gi]; }
+        else if (a.hist && gi >= -(long long)a.nhist) v = a.hist[a.nhist + gi];
+        x[m] = v;
+    }
+}
+
+template <class C, bool SCALED>
+__device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
+{
+    if (blk >= a.nblocks) return;
+    const long long base = blk * a.hop - a.ov;              // output index of window element 0
+    if constexpr (C::F == 1) {
+        long long left = a.n - base;
+        int bytes = (int)(left < C::N ? left : C::N) * 8;   // stores past the end are dropped by the range check
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + base, 0, bytes, 0x00020000);
+        const cf ss = mk(a.s_bwd, a.s_bwd);
 #pragma unroll
         for (int m = 0; m < C::P; m++) {
-            cf X = cscale(cswap(w[m]), a.s_fwd);            // Scale of vec_rfft
-            w[m] = cmul(X, H[m]);                           // vec_mul (vecops.rs:99-112)
-        }
-        fft_in_regs<C>(w, tw, lds, tid);                    // bwd = -j exponent
-        if (active) {
-            const long long out0 = blk * a.hop - a.ov + tid;    // output index of slot m=0 (may be < blk*hop)
-#pragma unroll
-            for (int m = 0; m < C::P; m++) {
-                const int e = tid + m * C::T;
-                const long long o = out0 + m * C::T;
-                if (e >= a.ov && o < a.n) a.out[o] = cscale(w[m], a.s_bwd);
+            const int e = tid + m * C::T;
+            if (e >= a.ov) {
+                cf v = SCALED ? cscale_k(w[m], ss) : w[m];
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, e * 8, 0, 0);
             }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < C::P; m++) {
+            const int e = tid + m * C::T;
+            const long long o = base + e;
+            if (e >= a.ov && o < a.n) a.out[o] = SCALED ? cscale(w[m], a.s_bwd) : w[m];
         }
     }
 }
 
-template <class C>
+// SCALED = false: both Scale factors are 1 (FIR: 1/N is folded into H)
+template <class C, bool SCALED, int MINW>
+__global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
+{
+    __shared__ cf lds_all[C::LDS_TOTAL];
+    // F == 1: the whole workgroup is one frame, so the block index stays provably wave-uniform
+    const int tid = (C::F == 1) ? (int)threadIdx.x : (int)(threadIdx.x % C::T);
+    const int fl = (C::F == 1) ? 0 : (int)(threadIdx.x / C::T);
+    cf *lds = lds_all + fl * C::LDS_FRAME;
+
+    const long long ngroups = (a.nblocks + C::F - 1) / C::F;
+    // software pipeline: the next block's window is in flight while this one is transformed.
+    // The first window goes out before the (L2-resident) tables so the HBM fetch starts at once.
+    cf nx[C::P];
+    load_window<C>(nx, a, (long long)blockIdx.x * C::F + fl, tid);
+
+    cf tw[C::TW];
+    if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
+    else load_twiddles<C>(tw, a.twN, tid);
+    cf H[C::P];
+#pragma unroll
+    for (int m = 0; m < C::P; m++) H[m] = a.Hf[tid + m * C::T];
+#pragma unroll 1
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long long blk = g * C::F + fl;
+        cf w[C::P];
+#pragma unroll
+        for (int m = 0; m < C::P; m++) w[m] = nx[m];
+        const long long gn = g + gridDim.x;
+        if (gn < ngroups && !(a.dbg & 1)) load_window<C>(nx, a, gn * C::F + fl, tid);
+
+        fft_in_regs<C, +1, 0>(w, tw, lds, tid);             // vec_rfft: the reference's fwd (+j exponent)
+        if constexpr (SCALED) {
+            const cf ss = mk(a.s_fwd, a.s_fwd);
+#pragma unroll
+            for (int m = 0; m < C::P; m++) w[m] = cscale_k(w[m], ss);       // Scale of vec_rfft
+        }
+#pragma unroll
+        for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);             // vec_mul (vecops.rs:99-112)
+        fft_in_regs<C, -1, fft_next_par<C>(0)>(w, tw, lds, tid);   // vec_rifft: bwd (-j); two transforms leave the parity even
+        if (!(a.dbg & 2)) store_block<C, SCALED>(w, a, blk, tid);
+    }
+}
+
+template <class C, bool SCALED>
 int launch_fmi(aeth_ctx *ctx, const FmiArgs &a)
 {
     long long ngroups = (a.nblocks + C::F - 1) / C::F;
-    long long cap = (long long)ctx->num_cus * 8;
+    long long cap = (long long)ctx->num_cus * 4;            // 2 waves/SIMD resident: 4 x 128-lane workgroups per CU
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((fmi_kernel<C>), dim3(grid), dim3(C::WG), 0, ctx->stream, a);
+    FmiArgs b = a;
+    { const char *d = getenv("AETH_FIR_DBG"); b.dbg = d ? atoi(d) : 0; if (b.dbg & 4) b.twL = nullptr; }
+    if constexpr (C::N == 2048) {
+        const char *g = getenv("AETH_FIR_GRID");
+        if (g) grid = atoi(g) < grid ? atoi(g) : grid;
+    }
+    if constexpr (C::N == 2048) {
+        const char *v = getenv("AETH_FIR_VARIANT");
+        if (v && atoi(v) == 3) { hipLaunchKernelGGL((fmi_kernel<C, SCALED, 3>), dim3(grid), dim3(C::WG), 0, ctx->stream, b); AETH_HIP(hipGetLastError()); return AETH_OK; }
+    }
+    hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1>), dim3(grid), dim3(C::WG), 0, ctx->stream, b);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
 
 int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a)
 {
-#define AETH_BODY(NN) return launch_fmi<typename CfgFor<NN>::type>(ctx, a)
+    const bool scaled = !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
+    {
+        const char *v = getenv("AETH_FIR_VARIANT");
+        if (fft_len == 2048 && v && atoi(v) == 8 && !scaled) { FmiArgs c = a; c.twL = nullptr; return launch_fmi<Cfg<2048, 8, 8, 8, 8, 4>, false>(ctx, c); }
+    }
+#define AETH_BODY(NN)                                                            \
+    return scaled ? launch_fmi<typename CfgFor<NN>::type, true>(ctx, a)          \
+                  : launch_fmi<typename CfgFor<NN>::type, false>(ctx, a)
     AETH_POW2_SWITCH(fft_len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "fused FFT*H*IFFT: length %zu", fft_len))
 #undef AETH_BODY
 }
@@ -149,8 +223,9 @@ int aeth_fft_mul_ifft(aeth_fft *plan, aeth_cf32 *frames, size_t n_total, size_t 
         return aeth_fft_exec(plan, frames, n_total, frames, batch, AETH_SIGN_REF_BWD, kind_bwd, x_bwd);
     }
     FmiArgs a;
+    a.dbg = 0;
     a.in = (const cf *)frames; a.out = (cf *)frames; a.hist = nullptr; a.Hf = (const cf *)sig;
-    a.twN = plan->tw_dev; a.n = (long long)n_total; a.nblocks = (long long)batch;
+    a.twN = (const cf *)plan->tw_dev; a.twL = (const cf *)plan->tw_lane_dev; a.n = (long long)n_total; a.nblocks = (long long)batch;
     a.hop = (int)plan->len; a.ov = 0; a.nhist = 0;
     a.s_fwd = aeth_scale_factor(kind_fwd, plan->len, x_fwd);
     a.s_bwd = aeth_scale_factor(kind_bwd, plan->len, x_bwd);
@@ -173,13 +248,13 @@ int aeth_fir_create(aeth_ctx *ctx, const aeth_cf32 *taps, size_t ntaps, size_t f
     f->hop = (L >= 64) ? (L / 64) * 64 : L;
     int rc = aeth_fft_create(ctx, fft_len, 1, &f->fft);
     if (rc == AETH_OK) {
-        hipError_t e = hipMalloc((void **)&f->Hf, fft_len * sizeof(cf));
+        hipError_t e = hipMalloc((void **)&f->Hf, fft_len * sizeof(float2));
         if (e != hipSuccess) rc = aeth::hip_fail(e, "hipMalloc");
     }
     if (rc == AETH_OK) {
         std::vector<aeth_cf32> padded(fft_len, aeth_cf32{0.f, 0.f});
         for (size_t k = 0; k < ntaps; k++) padded[k] = taps[k];
-        rc = aeth_upload(ctx, f->Hf, padded.data(), fft_len * sizeof(cf));
+        rc = aeth_upload(ctx, f->Hf, padded.data(), fft_len * sizeof(float2));
     }
     // H = fwd(taps || 0), then Scale::N folded in (x 1/N is exact for a power of two)
     if (rc == AETH_OK)
@@ -215,7 +290,8 @@ int aeth_fir_exec(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_
     AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out) && aeth::aligned8(hist), AETH_E_ALIGN,
                  "pointer not 8-byte aligned");
     FmiArgs a;
-    a.in = (const cf *)in; a.out = (cf *)out; a.hist = (const cf *)hist; a.Hf = f->Hf; a.twN = f->fft->tw_dev;
+    a.dbg = 0;
+    a.in = (const cf *)in; a.out = (cf *)out; a.hist = (const cf *)hist; a.Hf = (const cf *)f->Hf; a.twN = (const cf *)f->fft->tw_dev; a.twL = (const cf *)f->fft->tw_lane_dev;
     a.n = (long long)n; a.hop = (int)f->hop; a.ov = (int)(f->fft_len - f->hop); a.nhist = (int)(f->ntaps - 1);
     a.nblocks = (long long)((n + f->hop - 1) / f->hop);
     a.s_fwd = 1.0f; a.s_bwd = 1.0f;
@@ -229,12 +305,12 @@ int aeth_fir_exec_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, 
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
     aeth_ctx *ctx = f->ctx;
     const size_t nh = f->ntaps - 1;
-    const size_t bytes = n * sizeof(cf);
-    int rc = aeth::ctx_stage(ctx, 0, (n + nh) * sizeof(cf)); if (rc) return rc;
+    const size_t bytes = n * sizeof(float2);
+    int rc = aeth::ctx_stage(ctx, 0, (n + nh) * sizeof(float2)); if (rc) return rc;
     rc = aeth::ctx_stage(ctx, 1, bytes); if (rc) return rc;
-    cf *dh = (cf *)ctx->stage[0];
-    cf *din = dh + nh;     // nh*8 bytes in: keeps 8-byte alignment
-    if (hist && nh) AETH_HIP(hipMemcpyAsync(dh, hist, nh * sizeof(cf), hipMemcpyHostToDevice, ctx->stream));
+    float2 *dh = (float2 *)ctx->stage[0];
+    float2 *din = dh + nh;     // nh*8 bytes in: keeps 8-byte alignment
+    if (hist && nh) AETH_HIP(hipMemcpyAsync(dh, hist, nh * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     AETH_HIP(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = aeth_fir_exec(f, hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)din, n, (aeth_cf32 *)ctx->stage[1]);
     if (rc) return rc;

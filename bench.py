@@ -58,6 +58,7 @@ def cpu_baseline(budget_s=6.0):
     x = orc.synth_cnormal(815, n)
     taps = orc.synth_lowpass_taps(NTAPS, 0.25)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)      # the GPU box's CPU share for one GPU
     res = {}
     for label, th in (("1", 1), ("T", cores)):
         done, t0 = 0, time.perf_counter()

@@ -36,8 +36,15 @@ def test_fir_vs_direct_convolution(ctx, oracle, taps, n):
     f = Fir(ctx, taps, 2048)
     y = f.filter(ctx.vec(x)).to_host()
     truth = oracle.fir_direct_f64(taps, x)
-    assert oracle.evm_db(y, truth) <= TOL_DB
-    assert oracle.evm_db(y, oracle.fir_ols_f32(taps, x, 2048, f.hop)) <= TOL_DB
+    ols = oracle.fir_ols_f32(taps, x, 2048, f.hop)
+    if n >= 63:
+        assert oracle.evm_db(y, truth) <= TOL_DB
+        assert oracle.evm_db(y, ols) <= TOL_DB
+    else:
+        # a handful of start-up outputs: FFT convolution errors scale with the block, not the
+        # sample, so use an absolute bound (a few f32 ulps of max|x| * sum|h|)
+        bound = 4 * 2.0 ** -23 * float(np.abs(x).max()) * float(np.abs(taps).sum())
+        assert np.abs(y - truth).max() <= bound and np.abs(y - ols).max() <= bound
     # host-slice flavour gives the same bits
     assert bits_equal(f.filter(x), y)
 
