@@ -1,15 +1,299 @@
-// aeth_fft_big.hip -- transforms that do not fit one workgroup's LDS:
-// four-step power-of-two (N = N1 x N2) and Bluestein for arbitrary lengths.
+// aeth_fft_big.hip -- transforms that do not fit one workgroup's LDS.
+//
+// fourstep_pow2 (N = 2^13 .. 2^24, BASELINE config 5 uses 65536 = 256 x 256):
+//   x[n1*N2 + n2]  --A-->  a[k1*N2 + n2] = W_N^(n2*k1) * sum_n1 x[n1*N2+n2] W_N1^(n1*k1)
+//                  --B-->  X[k1 + N1*k2] = sum_n2 a[k1*N2+n2] W_N2^(n2*k2)
+//   A: a workgroup owns G adjacent columns (G*8 B contiguous per row: 128 B for G=16),
+//      one register-resident N1-point transform per column, twiddle, store in place
+//      layout into the plan's work buffer.
+//   B: a workgroup owns G adjacent rows (each row contiguous), one N2-point transform
+//      per row, then the N1-strided output is transposed through LDS so that stores
+//      again cover G adjacent k1 (128 B segments).
+//   HBM traffic 32 B/sample unless the 8 B/sample intermediate stays in the 256 MiB
+//   Infinity Cache (it does for batches up to ~16 frames of 65536).
+//
+// bluestein (any other length): chirp-z through a power-of-two circular convolution
+//   of length M >= 2N-1, itself run by the paths above.
 #include "aeth_internal.h"
 #include "aeth_fft_core.h"
 #include "aeth_fft_plan.h"
 
+#include <cmath>
+#include <vector>
+
+using namespace aeth::fftk;
+
+namespace {
+
+// single LDS image regardless of size (the column/row kernels hold G frames per workgroup)
+template <class C> struct OneImage : C { static constexpr bool DB = false; };
+
+template <class C> constexpr int group_of()
+{
+    // frames per workgroup: 16 for 128-byte segments, fewer when lanes or LDS run out
+    int g = 16;
+    while (g > 1 && (g * C::T > 1024 || g * C::LDS_FRAME * 8 > 64 * 1024)) g /= 2;
+    return g;
+}
+
+// ---- step A: G columns per workgroup ---------------------------------------------
+template <class C0, int S>
+__global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_cols(const cf *in, cf *work,
+                                                                          const cf *__restrict__ twL1,
+                                                                          const cf *__restrict__ twN, int N2, size_t N)
+{
+    using C = OneImage<C0>;
+    constexpr int G = group_of<C0>();
+    __shared__ cf lds_all[G * C::LDS_FRAME > 0 ? G * C::LDS_FRAME : 1];
+    const int col = threadIdx.x % G;
+    const int tid = threadIdx.x / G;
+    const int groups_per_frame = N2 / G;
+    const size_t frame = blockIdx.x / groups_per_frame;
+    const int n2 = (blockIdx.x % groups_per_frame) * G + col;
+    const cf *src = in + frame * N + n2;
+    cf *dst = work + frame * N + n2;
+    cf tw[C::TW];
+    load_twiddles_lane<C>(tw, twL1, tid);
+    cf w[C::P];
+#pragma unroll
+    for (int m = 0; m < C::P; m++) w[m] = src[(size_t)(tid + m * C::T) * N2];
+    fft_in_regs<C, S, 0>(w, tw, lds_all + col * C::LDS_FRAME, tid);
+#pragma unroll
+    for (int m = 0; m < C::P; m++) {
+        const int k1 = tid + m * C::T;
+        cf t = twN[(size_t)n2 * k1];                       // W_N^(n2*k1), n2*k1 < N
+        dst[(size_t)k1 * N2] = ctw<S>(w[m], t);
+    }
+}
+
+// ---- step B: G rows per workgroup, transposed store --------------------------------
+template <class C0, int S>
+__global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_rows(const cf *work, cf *out,
+                                                                          const cf *__restrict__ twL2, int N1, size_t N,
+                                                                          float scale)
+{
+    using C = OneImage<C0>;
+    constexpr int G = group_of<C0>();
+    constexpr int WGS = G * C::T;
+    constexpr int XP = C::N * (G + 1);                     // transpose image: [k2][row], one pad per k2
+    constexpr int FP = G * C::LDS_FRAME;
+    __shared__ cf lds_all[(XP > FP ? XP : FP)];
+    const int row = threadIdx.x / C::T;
+    const int tid = threadIdx.x % C::T;
+    const int groups_per_frame = N1 / G;
+    const size_t frame = blockIdx.x / groups_per_frame;
+    const int k1_0 = (blockIdx.x % groups_per_frame) * G;
+    const cf *src = work + frame * N + (size_t)(k1_0 + row) * C::N + tid;
+    cf tw[C::TW];
+    load_twiddles_lane<C>(tw, twL2, tid);
+    cf w[C::P];
+#pragma unroll
+    for (int m = 0; m < C::P; m++) w[m] = src[m * C::T];
+    fft_in_regs<C, S, 0>(w, tw, lds_all + row * C::LDS_FRAME, tid);
+    __syncthreads();                                       // the transform's LDS image is dead
+    const cf ss = mk(scale, scale);
+#pragma unroll
+    for (int m = 0; m < C::P; m++) lds_all[(tid + m * C::T) * (G + 1) + row] = cscale_k(w[m], ss);
+    __syncthreads();
+    const int r2 = threadIdx.x % G;                        // adjacent lanes -> adjacent k1
+    const int kk = threadIdx.x / G;
+    cf *dst = out + frame * N + k1_0 + r2;
+#pragma unroll
+    for (int j = 0; j < C::N * G / WGS; j++) {
+        const int k2 = kk + j * (WGS / G);
+        dst[(size_t)k2 * N1] = lds_all[k2 * (G + 1) + r2];
+    }
+}
+
+template <class C, int S>
+int launch_cols(aeth_fft *plan, const float2 *in, size_t batch)
+{
+    constexpr int G = group_of<C>();
+    const size_t grid = batch * (plan->n2 / G);
+    hipLaunchKernelGGL((fourstep_cols<C, S>), dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
+                       (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
+                       (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+template <class C, int S>
+int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale)
+{
+    constexpr int G = group_of<C>();
+    const size_t grid = batch * (plan->n1 / G);
+    hipLaunchKernelGGL((fourstep_rows<C, S>), dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
+                       (const cf *)plan->work_dev, (cf *)out, (const cf *)plan->sub2->tw_lane_dev, (int)plan->n1,
+                       plan->len, scale);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+int ensure_work(aeth_fft *plan, size_t elems)
+{
+    if (plan->work_elems >= elems) return AETH_OK;
+    if (plan->work_dev) {
+        AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+        AETH_HIP(hipFree(plan->work_dev));
+        plan->work_dev = nullptr;
+        plan->work_elems = 0;
+    }
+    AETH_HIP(hipMalloc((void **)&plan->work_dev, elems * sizeof(float2)));
+    plan->work_elems = elems;
+    return AETH_OK;
+}
+
+// ---- bluestein helpers ---------------------------------------------------------------
+constexpr int kBlock = 256;
+
+// a[f*M + n] = (n < N) ? x[f*N + n] (conj if CONJ) * chirp[n] : 0
+template <bool CONJ>
+__global__ __launch_bounds__(kBlock) void blu_pre(const cf *__restrict__ x, const cf *__restrict__ chirp,
+                                                  cf *__restrict__ a, size_t N, size_t M, size_t batch)
+{
+    const size_t total = M * batch;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        size_t f = i / M, n = i - f * M;
+        cf v = mk(0.f, 0.f);
+        if (n < N) {
+            cf xv = x[f * N + n];
+            if (CONJ) xv.y = -xv.y;
+            v = cmul_plain(xv, chirp[n]);
+        }
+        a[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void blu_mul(cf *__restrict__ a, const cf *__restrict__ filt, size_t M, size_t batch)
+{
+    const size_t total = M * batch;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
+        a[i] = cmul_plain(a[i], filt[i % M]);
+}
+
+template <bool CONJ>
+__global__ __launch_bounds__(kBlock) void blu_post(const cf *__restrict__ a, const cf *__restrict__ chirp,
+                                                   cf *__restrict__ out, size_t N, size_t M, size_t batch, float scale)
+{
+    const size_t total = N * batch;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        size_t f = i / N, k = i - f * N;
+        cf v = cmul_plain(a[f * M + k], chirp[k]);
+        if (CONJ) v.y = -v.y;
+        out[i] = cscale(v, scale);
+    }
+}
+
+inline int grid_for(const aeth_ctx *ctx, size_t items)
+{
+    size_t blocks = (items + kBlock - 1) / kBlock;
+    size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
 namespace aeth {
 
-int fft_plan_fourstep(aeth_fft *plan) { return set_error(AETH_E_UNSUPPORTED, "fourstep_pow2 not built yet (length %zu)", plan->len); }
-int fft_run_fourstep(aeth_fft *plan, const float2 *, float2 *, size_t, int, float) { return set_error(AETH_E_UNSUPPORTED, "fourstep_pow2 not built yet (length %zu)", plan->len); }
-int fft_plan_bluestein(aeth_fft *plan) { return set_error(AETH_E_UNSUPPORTED, "bluestein not built yet (length %zu)", plan->len); }
-int fft_run_bluestein(aeth_fft *plan, const float2 *, float2 *, size_t, int, float) { return set_error(AETH_E_UNSUPPORTED, "bluestein not built yet (length %zu)", plan->len); }
-void fft_plan_release_children(aeth_fft *) {}
+// ------------------------------- four-step --------------------------------------------
+int fft_plan_fourstep(aeth_fft *plan)
+{
+    int k = 0;
+    while (((size_t)1 << k) < plan->len) k++;
+    plan->n1 = (size_t)1 << (k / 2);
+    plan->n2 = plan->len / plan->n1;
+    if (plan->n1 < 16 || plan->n2 > 4096) return set_error(AETH_E_UNSUPPORTED, "fourstep_pow2: length %zu", plan->len);
+    int rc = aeth_fft_create(plan->ctx, plan->n1, 1, &plan->sub1);
+    if (rc) return rc;
+    return aeth_fft_create(plan->ctx, plan->n2, 1, &plan->sub2);
+}
+
+int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+{
+    int rc = ensure_work(plan, plan->len * batch);
+    if (rc) return rc;
+#define AETH_BODY(NN)                                                                                   \
+    return sign > 0 ? launch_cols<typename CfgFor<NN>::type, +1>(plan, in, batch)                       \
+                    : launch_cols<typename CfgFor<NN>::type, -1>(plan, in, batch)
+    auto cols = [&]() -> int { AETH_POW2_SWITCH(plan->n1, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n1")) };
+#undef AETH_BODY
+#define AETH_BODY(NN)                                                                                   \
+    return sign > 0 ? launch_rows<typename CfgFor<NN>::type, +1>(plan, out, batch, scale)               \
+                    : launch_rows<typename CfgFor<NN>::type, -1>(plan, out, batch, scale)
+    auto rows = [&]() -> int { AETH_POW2_SWITCH(plan->n2, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n2")) };
+#undef AETH_BODY
+    rc = cols();
+    if (rc) return rc;
+    return rows();
+}
+
+// ------------------------------- bluestein --------------------------------------------
+int fft_plan_bluestein(aeth_fft *plan)
+{
+    const size_t N = plan->len;
+    size_t M = 1;
+    while (M < 2 * N - 1) M <<= 1;
+    plan->blu_m = M;
+    int rc = aeth_fft_create(plan->ctx, M, 1, &plan->blu_sub);
+    if (rc) return rc;
+    // chirp[k] = exp(-j pi k^2 / N), k^2 reduced mod 2N in integers to keep the angle exact
+    std::vector<float2> chirp(N), filt(M, make_float2(0.f, 0.f));
+    for (size_t k = 0; k < N; k++) {
+        unsigned long long q = ((unsigned long long)k * k) % (2ull * N);
+        double ang = -M_PI * (double)q / (double)N;
+        chirp[k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    // filter b[n] = conj(chirp[|n|]) wrapped to length M
+    for (size_t k = 0; k < N; k++) {
+        float2 c = make_float2(chirp[k].x, -chirp[k].y);
+        filt[k] = c;
+        if (k) filt[M - k] = c;
+    }
+    AETH_HIP(hipMalloc((void **)&plan->blu_chirp, N * sizeof(float2)));
+    AETH_HIP(hipMalloc((void **)&plan->blu_filt, M * sizeof(float2)));
+    rc = aeth_upload(plan->ctx, plan->blu_chirp, chirp.data(), N * sizeof(float2));
+    if (rc) return rc;
+    rc = aeth_upload(plan->ctx, plan->blu_filt, filt.data(), M * sizeof(float2));
+    if (rc) return rc;
+    // Bf = DFT-(b) / M : the 1/M of the inverse transform is folded in (exact, M is a power of two)
+    rc = fft_run(plan->blu_sub, plan->blu_filt, plan->blu_filt, 1, -1, 1.0f / (float)M);
+    if (rc) return rc;
+    return aeth_ctx_sync(plan->ctx);
+}
+
+int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+{
+    const size_t N = plan->len, M = plan->blu_m;
+    int rc = ensure_work(plan, M * batch);
+    if (rc) return rc;
+    aeth_ctx *ctx = plan->ctx;
+    cf *a = (cf *)plan->work_dev;
+    const dim3 b(kBlock);
+    // DFT+(x) = conj(DFT-(conj x))
+    if (sign > 0) hipLaunchKernelGGL((blu_pre<true>), dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
+    else          hipLaunchKernelGGL((blu_pre<false>), dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
+    AETH_HIP(hipGetLastError());
+    rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, -1, 1.0f);
+    if (rc) return rc;
+    hipLaunchKernelGGL(blu_mul, dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, a, (const cf *)plan->blu_filt, M, batch);
+    AETH_HIP(hipGetLastError());
+    rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, +1, 1.0f);
+    if (rc) return rc;
+    if (sign > 0) hipLaunchKernelGGL((blu_post<true>), dim3(grid_for(ctx, N * batch)), b, 0, ctx->stream, (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
+    else          hipLaunchKernelGGL((blu_post<false>), dim3(grid_for(ctx, N * batch)), b, 0, ctx->stream, (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+void fft_plan_release_children(aeth_fft *plan)
+{
+    if (plan->sub1) { aeth_fft_destroy(plan->sub1); plan->sub1 = nullptr; }
+    if (plan->sub2) { aeth_fft_destroy(plan->sub2); plan->sub2 = nullptr; }
+    if (plan->blu_sub) { aeth_fft_destroy(plan->blu_sub); plan->blu_sub = nullptr; }
+    if (plan->work_dev) { (void)hipFree(plan->work_dev); plan->work_dev = nullptr; plan->work_elems = 0; }
+    if (plan->blu_chirp) { (void)hipFree(plan->blu_chirp); plan->blu_chirp = nullptr; }
+    if (plan->blu_filt) { (void)hipFree(plan->blu_filt); plan->blu_filt = nullptr; }
+}
 
 }  // namespace aeth

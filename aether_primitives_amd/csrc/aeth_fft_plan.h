@@ -19,6 +19,7 @@ struct aeth_fft {
     std::vector<int> factors;        // stockham_mixed radix schedule
     // fourstep_pow2: len = n1 * n2
     size_t n1 = 0, n2 = 0;
+    aeth_fft *sub1 = nullptr, *sub2 = nullptr;   // the N1- and N2-point plans (per-lane twiddle tables)
     float2 *work_dev = nullptr;      // intermediate of the two launches (len * batch)
     size_t work_elems = 0;
     // bluestein: convolution length m (power of two), sub-plan, chirps
