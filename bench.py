@@ -77,6 +77,22 @@ def cpu_baseline(budget_s=6.0):
                       f"same taps and FFT-2048 geometry as the GPU run"}
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC
+    summary (profiles/rNN_summary.json: separate FETCH_SIZE / WRITE_SIZE passes over this
+    same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no profile is there."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if "hbm_bytes_per_launch" in d:
+                best = (os.path.basename(f), d["hbm_bytes_per_launch"])
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap_ = argparse.ArgumentParser()
     ap_.add_argument("--gpus", type=int, default=1)
@@ -156,7 +172,9 @@ def main():
                        "fft_len": FFT_LEN, "ntaps": NTAPS, "hop": fir.hop, "samples_per_step": STREAM,
                        "parallelism": f"{args.gpus} independent stream(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (measured_traffic() or (None, None))[1],
+                         "traffic_source": (measured_traffic() or (None, None))[0],
                          "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>>", "kernel_ms": round(kern_ms, 5),
                          "bytes_per_launch": BYTES_PER_SAMPLE * STREAM},
             "pct_of_hbm_roofline": round(100.0 * value / args.gpus * BYTES_PER_SAMPLE / HBM_PEAK_GBS, 2),

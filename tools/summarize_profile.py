@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 csv) into profiles/<tag>_*.{csv,json}.
+
+HBM traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
+collected in separate --pmc passes, are reported in KiB, and on gfx950 FETCH_SIZE
+counts 64 B per 128-B request of a wide coalesced stream, i.e. it reads HALF the
+fetched bytes -> doubled here; WRITE_SIZE is exact for streaming stores."""
+import csv, glob, json, os, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+KERNEL = "fmi_kernel"
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern))
+    return f[0] if f else None
+
+
+out = {"tag": tag, "command": "python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"}
+st = one("trace/*/*_kernel_stats.csv")
+if st:
+    rows = list(csv.DictReader(open(st)))
+    with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
+    for r in rows:
+        if KERNEL in r["Name"]:
+            out["kernel"] = r["Name"]; out["calls"] = int(r["Calls"])
+            out["avg_ns"] = float(r["AverageNs"]); out["min_ns"] = float(r["MinNs"]); out["max_ns"] = float(r["MaxNs"])
+for key, pat in (("FETCH_SIZE", "fetch/*/*_counter_collection.csv"), ("WRITE_SIZE", "write/*/*_counter_collection.csv")):
+    f = one(pat)
+    if not f:
+        continue
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == key]
+    if vals:
+        vals = vals[len(vals) // 10:]          # drop warm-up launches
+        out[key + "_KiB_per_launch_raw"] = sum(vals) / len(vals)
+for name in ("trace", "fetch", "write"):
+    p = os.path.join(src, f"{name}_bench.json")
+    if os.path.exists(p):
+        try:
+            out[f"bench_line_{name}"] = json.loads(open(p).read().strip().splitlines()[-1])
+        except Exception:
+            pass
+if "FETCH_SIZE_KiB_per_launch_raw" in out and "WRITE_SIZE_KiB_per_launch_raw" in out:
+    rd = out["FETCH_SIZE_KiB_per_launch_raw"] * 1024 * 2        # gfx950 correction: x2 (see docstring)
+    wr = out["WRITE_SIZE_KiB_per_launch_raw"] * 1024
+    out["hbm_read_bytes_per_launch"] = rd
+    out["hbm_write_bytes_per_launch"] = wr
+    out["hbm_bytes_per_launch"] = rd + wr
+    out["algorithmic_bytes_per_launch"] = 16 * (1 << 24)
+    out["traffic_over_algorithmic"] = (rd + wr) / (16 * (1 << 24))
+json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if not k.startswith("bench_line")}, indent=1))
