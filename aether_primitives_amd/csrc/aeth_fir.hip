@@ -75,6 +75,10 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
 #pragma unroll
             for (int m = 0; m < C::P; m++)
                 x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 0));
+            // window samples older than the ntaps-1 the outputs depend on are forced to zero, so a
+            // block is a function of exactly x[out0-(ntaps-1) .. out0+hop): shards of one stream
+            // (history = ntaps-1 samples) then reproduce the unsharded run bit for bit
+            if (tid < a.ov - a.nhist) x[0] = mk(0.f, 0.f);
             return;
         }
     }
@@ -82,8 +86,10 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
     for (int m = 0; m < C::P; m++) {
         const long long gi = win0 + tid + m * C::T;
         cf v = mk(0.f, 0.f);
-        if (gi >= 0) { if (gi < a.n) v = a.in[gi]; }
-        else if (a.hist && gi >= -(long long)a.nhist) v = a.hist[a.nhist + gi];
+        if (tid + m * C::T >= a.ov - a.nhist) {
+            if (gi >= 0) { if (gi < a.n) v = a.in[gi]; }
+            else if (a.hist && gi >= -(long long)a.nhist) v = a.hist[a.nhist + gi];
+        }
         x[m] = v;
     }
 }

@@ -1,0 +1,288 @@
+// aether_hip.hpp -- header-only C++17 host wrapper over the C ABI (aether_hip.h).
+//
+// The reference is Rust; its toolchain is absent from this pipeline, so the host
+// side above the C ABI is mirrored here in C++ with the reference's own names,
+// argument meaning and error behaviour:
+//   aether::Scale            <-> enum Scale              (src/fft.rs:6-38)
+//   aether::Fft / HipFft     <-> trait Fft / struct Cfft (src/fft.rs:48-77, :134-235)
+//   aether::DeviceVec        <-> trait VecOps on [cf32]  (src/vecops.rs:39-89), device-resident
+//   aether::HostVec          <-> the same on a host slice (one H2D + D2H per call)
+//   aether::interpolate / downsample                     (src/sampling.rs:7-62)
+//   aether::assert_evm                                   (src/lib.rs:26-49)
+// The reference panics on misuse (assert_eq!); here the same conditions throw
+// aether::Panic carrying the reference's message text.
+#pragma once
+
+#include <cmath>
+#include <complex>
+#include <cstddef>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "aether_hip.h"
+
+namespace aether {
+
+using cf32 = std::complex<float>;     // layout-compatible with aeth_cf32 / Complex<f32>
+static_assert(sizeof(cf32) == sizeof(aeth_cf32), "cf32 layout");
+
+struct Panic : std::runtime_error {
+    int code;
+    Panic(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc)
+{
+    if (rc != AETH_OK) throw Panic(rc, aeth_last_error());
+}
+
+inline aeth_cf32 *raw(cf32 *p) { return reinterpret_cast<aeth_cf32 *>(p); }
+inline const aeth_cf32 *raw(const cf32 *p) { return reinterpret_cast<const aeth_cf32 *>(p); }
+
+// ---- enum Scale (src/fft.rs:6-18) ------------------------------------------------
+struct Scale {
+    int kind;
+    float x;
+    static Scale None() { return {AETH_SCALE_NONE, 0.f}; }
+    static Scale SN() { return {AETH_SCALE_SN, 0.f}; }
+    static Scale N() { return {AETH_SCALE_N, 0.f}; }
+    static Scale X(float v) { return {AETH_SCALE_X, v}; }
+    float factor(size_t n) const { return aeth_scale_factor(kind, n, x); }
+};
+
+class Context {
+public:
+    explicit Context(int device = 0) { check(aeth_ctx_create(device, &h_)); }
+    ~Context() { aeth_ctx_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    aeth_ctx *get() const { return h_; }
+    void sync() const { check(aeth_ctx_sync(h_)); }
+
+private:
+    aeth_ctx *h_ = nullptr;
+};
+
+class HipFft;
+
+// ---- trait VecOps, device-resident receiver (src/vecops.rs:39-89) ------------------
+class DeviceVec {
+public:
+    DeviceVec(Context &ctx, size_t n) : ctx_(&ctx), n_(n), own_(true)
+    {
+        void *p = nullptr;
+        check(aeth_dev_alloc(ctx.get(), (n ? n : 1) * sizeof(aeth_cf32), &p));
+        p_ = static_cast<aeth_cf32 *>(p);
+    }
+    DeviceVec(Context &ctx, const std::vector<cf32> &host) : DeviceVec(ctx, host.size())
+    {
+        check(aeth_upload(ctx.get(), p_, host.data(), host.size() * sizeof(cf32)));
+    }
+    // borrowed view `self[start..stop]`
+    DeviceVec(DeviceVec &parent, size_t start, size_t stop)
+        : ctx_(parent.ctx_), p_(parent.p_ + start), n_(stop - start), own_(false)
+    {
+        if (start > stop || stop > parent.n_) throw Panic(AETH_E_LEN, "slice index out of range");
+    }
+    ~DeviceVec() { if (own_ && p_) aeth_dev_free(ctx_->get(), p_); }
+    DeviceVec(const DeviceVec &) = delete;
+    DeviceVec &operator=(const DeviceVec &) = delete;
+    DeviceVec(DeviceVec &&o) noexcept : ctx_(o.ctx_), p_(o.p_), n_(o.n_), own_(o.own_) { o.p_ = nullptr; o.own_ = false; }
+
+    size_t len() const { return n_; }
+    aeth_cf32 *ptr() const { return p_; }
+    Context &ctx() const { return *ctx_; }
+    std::vector<cf32> to_host() const
+    {
+        std::vector<cf32> h(n_);
+        check(aeth_download(ctx_->get(), h.data(), p_, n_ * sizeof(cf32)));
+        return h;
+    }
+
+    DeviceVec &vec_scale(float s) { check(aeth_vec_scale(c(), p_, n_, s)); return *this; }
+    DeviceVec &vec_mul(const DeviceVec &o) { check(aeth_vec_mul(c(), p_, n_, o.p_, o.n_)); return *this; }
+    DeviceVec &vec_div(const DeviceVec &o) { check(aeth_vec_div(c(), p_, n_, o.p_, o.n_)); return *this; }
+    DeviceVec &vec_conj() { check(aeth_vec_conj(c(), p_, n_)); return *this; }
+    DeviceVec &vec_mirror() { check(aeth_vec_mirror(c(), p_, n_)); return *this; }
+    DeviceVec &vec_clone(const DeviceVec &o) { check(aeth_vec_clone(c(), p_, n_, o.p_, o.n_)); return *this; }
+    DeviceVec &vec_zero() { check(aeth_vec_zero(c(), p_, n_)); return *this; }
+    DeviceVec &vec_add(const DeviceVec &o) { check(aeth_vec_add(c(), p_, n_, o.p_, o.n_)); return *this; }
+    DeviceVec &vec_sub(const DeviceVec &o) { check(aeth_vec_sub(c(), p_, n_, o.p_, o.n_)); return *this; }
+    // closure per element, in order (src/vecops.rs:179-182): cannot cross the FFI, so
+    // the data takes a round trip through the host -- slow by design.
+    DeviceVec &vec_mutate(const std::function<void(cf32 &)> &f)
+    {
+        auto h = to_host();
+        for (auto &z : h) f(z);
+        check(aeth_upload(c(), p_, h.data(), n_ * sizeof(cf32)));
+        return *this;
+    }
+    inline DeviceVec &vec_fft(Scale s);                    // fresh plan (src/vecops.rs:185-189)
+    inline DeviceVec &vec_ifft(Scale s);
+    inline DeviceVec &vec_rfft(HipFft &fft, Scale s);      // reused plan (src/vecops.rs:198-207)
+    inline DeviceVec &vec_rifft(HipFft &fft, Scale s);
+
+private:
+    aeth_ctx *c() const { return ctx_->get(); }
+    Context *ctx_;
+    aeth_cf32 *p_ = nullptr;
+    size_t n_ = 0;
+    bool own_ = false;
+};
+
+// ---- trait Fft (src/fft.rs:48-77) ---------------------------------------------------
+struct Fft {
+    virtual ~Fft() = default;
+    virtual void fwd(const cf32 *input, size_t n_in, cf32 *output, size_t n_out, Scale s) = 0;
+    virtual void bwd(const cf32 *input, size_t n_in, cf32 *output, size_t n_out, Scale s) = 0;
+    virtual void ifwd(cf32 *input, size_t n, Scale s) = 0;
+    virtual void ibwd(cf32 *input, size_t n, Scale s) = 0;
+    virtual const cf32 *tfwd(const cf32 *input, size_t n, Scale s) = 0;
+    virtual const cf32 *tbwd(const cf32 *input, size_t n, Scale s) = 0;
+    virtual size_t len() const = 0;
+};
+
+// `impl Fft for HipFft`: plugs in where the reference's Cfft does (src/fft.rs:134-235).
+// The exponent sign is bound to the method names HERE and nowhere else.
+class HipFft final : public Fft {
+public:
+    static constexpr int kFwdSign = AETH_SIGN_REF_FWD;     // Cfft plans fwd with inverse=true (src/fft.rs:148)
+    static constexpr int kBwdSign = AETH_SIGN_REF_BWD;
+    HipFft(Context &ctx, size_t len, size_t max_batch = 1) { check(aeth_fft_create(ctx.get(), len, max_batch, &h_)); }
+    static HipFft with_len(Context &ctx, size_t len) { return HipFft(ctx, len); }      // Cfft::with_len
+    ~HipFft() override { aeth_fft_destroy(h_); }
+    HipFft(const HipFft &) = delete;
+    HipFft(HipFft &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+
+    // host slices: the literal trait methods
+    void fwd(const cf32 *in, size_t n_in, cf32 *out, size_t n_out, Scale s) override { check(aeth_fft_exec_host(h_, raw(in), n_in, raw(out), n_out, kFwdSign, s.kind, s.x)); }
+    void bwd(const cf32 *in, size_t n_in, cf32 *out, size_t n_out, Scale s) override { check(aeth_fft_exec_host(h_, raw(in), n_in, raw(out), n_out, kBwdSign, s.kind, s.x)); }
+    void ifwd(cf32 *io, size_t n, Scale s) override { check(aeth_fft_exec_host(h_, raw(io), n, raw(io), n, kFwdSign, s.kind, s.x)); }
+    void ibwd(cf32 *io, size_t n, Scale s) override { check(aeth_fft_exec_host(h_, raw(io), n, raw(io), n, kBwdSign, s.kind, s.x)); }
+    const cf32 *tfwd(const cf32 *in, size_t n, Scale s) override { return tmp(in, n, kFwdSign, s); }
+    const cf32 *tbwd(const cf32 *in, size_t n, Scale s) override { return tmp(in, n, kBwdSign, s); }
+    size_t len() const override { return aeth_fft_len(h_); }
+
+    // device-resident frames (len(v) = batch * len()), stream-ordered
+    void fwd(const DeviceVec &in, DeviceVec &out, Scale s) { exec(in, out, kFwdSign, s); }
+    void bwd(const DeviceVec &in, DeviceVec &out, Scale s) { exec(in, out, kBwdSign, s); }
+    void ifwd(DeviceVec &io, Scale s) { exec(io, io, kFwdSign, s); }
+    void ibwd(DeviceVec &io, Scale s) { exec(io, io, kBwdSign, s); }
+    // frames.vec_rfft(s).vec_mul(sig).vec_rifft(s) fused (benches/benches.rs:410-416)
+    void mul_chain(DeviceVec &frames, const DeviceVec &sig, Scale s_fwd, Scale s_bwd)
+    {
+        size_t n = len();
+        check(aeth_fft_mul_ifft(h_, frames.ptr(), frames.len(), n ? frames.len() / n : 0, sig.ptr(), sig.len(),
+                                s_fwd.kind, s_fwd.x, s_bwd.kind, s_bwd.x));
+    }
+    aeth_fft *get() const { return h_; }
+
+private:
+    void exec(const DeviceVec &in, DeviceVec &out, int sign, Scale s)
+    {
+        if (out.len() != in.len()) throw Panic(AETH_E_LEN, "Output and FFT must be the same length");
+        size_t n = len();
+        check(aeth_fft_exec(h_, in.ptr(), in.len(), out.ptr(), n ? in.len() / n : 0, sign, s.kind, s.x));
+    }
+    const cf32 *tmp(const cf32 *in, size_t n, int sign, Scale s)
+    {
+        const aeth_cf32 *view = nullptr;
+        check(aeth_fft_exec_tmp_host(h_, raw(in), n, sign, s.kind, s.x, &view));
+        return reinterpret_cast<const cf32 *>(view);
+    }
+    aeth_fft *h_ = nullptr;
+};
+
+inline DeviceVec &DeviceVec::vec_fft(Scale s) { HipFft f(*ctx_, n_); f.ifwd(*this, s); return *this; }
+inline DeviceVec &DeviceVec::vec_ifft(Scale s) { HipFft f(*ctx_, n_); f.ibwd(*this, s); return *this; }
+inline DeviceVec &DeviceVec::vec_rfft(HipFft &fft, Scale s) { fft.ifwd(*this, s); return *this; }
+inline DeviceVec &DeviceVec::vec_rifft(HipFft &fft, Scale s) { fft.ibwd(*this, s); return *this; }
+
+// ---- VecOps on a host slice: the literal drop-in receiver ----------------------------
+class HostVec {
+public:
+    HostVec(Context &ctx, cf32 *data, size_t n) : ctx_(&ctx), p_(data), n_(n) {}
+    HostVec(Context &ctx, std::vector<cf32> &v) : HostVec(ctx, v.data(), v.size()) {}
+    HostVec &vec_scale(float s) { check(aeth_host_vec_scale(c(), raw(p_), n_, s)); return *this; }
+    HostVec &vec_mul(const std::vector<cf32> &o) { check(aeth_host_vec_mul(c(), raw(p_), n_, raw(o.data()), o.size())); return *this; }
+    HostVec &vec_div(const std::vector<cf32> &o) { check(aeth_host_vec_div(c(), raw(p_), n_, raw(o.data()), o.size())); return *this; }
+    HostVec &vec_conj() { check(aeth_host_vec_conj(c(), raw(p_), n_)); return *this; }
+    HostVec &vec_mirror() { check(aeth_host_vec_mirror(c(), raw(p_), n_)); return *this; }
+    HostVec &vec_clone(const std::vector<cf32> &o) { check(aeth_host_vec_clone(c(), raw(p_), n_, raw(o.data()), o.size())); return *this; }
+    HostVec &vec_zero() { check(aeth_host_vec_zero(c(), raw(p_), n_)); return *this; }
+    HostVec &vec_add(const std::vector<cf32> &o) { check(aeth_host_vec_add(c(), raw(p_), n_, raw(o.data()), o.size())); return *this; }
+    HostVec &vec_sub(const std::vector<cf32> &o) { check(aeth_host_vec_sub(c(), raw(p_), n_, raw(o.data()), o.size())); return *this; }
+    HostVec &vec_mutate(const std::function<void(cf32 &)> &f) { for (size_t i = 0; i < n_; i++) f(p_[i]); return *this; }
+    HostVec &vec_fft(Scale s) { HipFft f(*ctx_, n_); f.ifwd(p_, n_, s); return *this; }
+    HostVec &vec_ifft(Scale s) { HipFft f(*ctx_, n_); f.ibwd(p_, n_, s); return *this; }
+    HostVec &vec_rfft(Fft &fft, Scale s) { fft.ifwd(p_, n_, s); return *this; }
+    HostVec &vec_rifft(Fft &fft, Scale s) { fft.ibwd(p_, n_, s); return *this; }
+
+private:
+    aeth_ctx *c() const { return ctx_->get(); }
+    Context *ctx_;
+    cf32 *p_;
+    size_t n_;
+};
+
+// ---- FIR (src/fir.rs:3-22 has the struct, not the filter) ------------------------------
+class Fir {
+public:
+    Fir(Context &ctx, const std::vector<cf32> &taps, size_t fft_len = 2048) { check(aeth_fir_create(ctx.get(), raw(taps.data()), taps.size(), fft_len, &h_)); }
+    ~Fir() { aeth_fir_destroy(h_); }
+    Fir(const Fir &) = delete;
+    size_t hop() const { return aeth_fir_hop(h_); }
+    void filter(const DeviceVec &x, DeviceVec &y, const DeviceVec *hist = nullptr)
+    {
+        if (y.len() != x.len()) throw Panic(AETH_E_LEN, "Vectors must have same length");
+        check(aeth_fir_exec(h_, hist ? hist->ptr() : nullptr, x.ptr(), x.len(), y.ptr()));
+    }
+    void filter(const std::vector<cf32> &x, std::vector<cf32> &y)
+    {
+        y.resize(x.size());
+        check(aeth_fir_exec_host(h_, nullptr, raw(x.data()), x.size(), raw(y.data())));
+    }
+
+private:
+    aeth_fir *h_ = nullptr;
+};
+
+// ---- sampling (src/sampling.rs) ---------------------------------------------------------
+// appends to dst, as the reference does (sampling.rs:17,23)
+inline void interpolate(Context &ctx, const std::vector<cf32> &src, std::vector<cf32> &dst, size_t n_between,
+                        bool compat_im = true)
+{
+    if (src.empty()) throw Panic(AETH_E_LEN, "interpolate on an empty src (the reference panics: sampling.rs:23)");
+    const size_t add = src.size() + (src.size() - 1) * n_between, old = dst.size();
+    dst.resize(old + add);
+    size_t written = 0;
+    check(aeth_host_interpolate(ctx.get(), raw(src.data()), src.size(), raw(dst.data() + old), add, n_between,
+                                compat_im ? 1 : 0, &written));
+    dst.resize(old + written);
+}
+
+template <typename T>
+inline void downsample(Context &ctx, const std::vector<T> &src, std::vector<T> &dst)
+{
+    check(aeth_host_downsample(ctx.get(), src.data(), src.size(), dst.data(), dst.size(), sizeof(T)));
+}
+template <typename T>
+inline void downsample_sb(Context &ctx, const std::vector<T> &src, std::vector<T> &dst) { downsample(ctx, src, dst); }
+
+// ---- assert_evm! (src/lib.rs:26-49), literal, plus a NaN reject ---------------------------
+inline void assert_evm(const std::vector<cf32> &actual, const std::vector<cf32> &ref, double evm_limit_db = -80.0)
+{
+    if (actual.size() != ref.size()) throw Panic(AETH_E_LEN, "Input slices/vectors must be same length");
+    if (!(evm_limit_db < 0.0)) throw Panic(AETH_E_ARG, "The EVM threshold must be negative");
+    const float fac = (float)std::pow(10.0, evm_limit_db / 10.0);
+    for (size_t i = 0; i < actual.size(); i++) {
+        const float evm = std::abs(actual[i] - ref[i]);
+        const float limit = std::abs(ref[i]) * fac;
+        if (evm > limit || std::isnan(actual[i].real()) || std::isnan(actual[i].imag()))
+            throw Panic(AETH_E_ARG, "EVM limit exceeded for element " + std::to_string(i));
+    }
+}
+
+}  // namespace aether

@@ -258,14 +258,17 @@ static void ols_block(orc_fft_plan *plan, const orc_cf32 *Hf, size_t fft_len, or
     orc_cfft_inplace(plan, blk, fft_len, ORC_SIGN_REF_BWD, ORC_SCALE_N, 0.0f);
 }
 
-static void ols_fill_block(orc_cf32 *blk, size_t fft_len, size_t ntaps, const orc_cf32 *hist,
+static void ols_fill_block(orc_cf32 *blk, size_t fft_len, size_t ntaps, size_t hop, const orc_cf32 *hist,
                            const orc_cf32 *x, size_t n, size_t out0)
 {
-    /* block covers input samples [out0-(ntaps-1) , out0-(ntaps-1)+fft_len) */
+    /* the block holds exactly the samples its hop outputs depend on,
+     * x[out0-(ntaps-1) .. out0+hop), and zeros elsewhere: a block's result is then a
+     * function of those samples alone, whatever stream or shard it is cut from */
     const size_t ov = ntaps - 1;
     for (size_t j = 0; j < fft_len; j++) {
         long long idx = (long long)out0 - (long long)ov + (long long)j;
-        if (idx < 0) {
+        if (j >= ov + hop) { blk[j].re = 0; blk[j].im = 0; }
+        else if (idx < 0) {
             if (hist) blk[j] = hist[(long long)ov + idx];
             else { blk[j].re = 0; blk[j].im = 0; }
         } else if ((size_t)idx < n) blk[j] = x[idx];
@@ -289,7 +292,7 @@ int orc_fir_ols_f32(const orc_cf32 *h, size_t ntaps, size_t fft_len, size_t hop,
     orc_cf32 *Hf = ols_taps_freq(plan, h, ntaps, fft_len);
     orc_cf32 *blk = (orc_cf32 *)malloc(fft_len * sizeof(orc_cf32));
     for (size_t out0 = 0; out0 < n; out0 += hop) {
-        ols_fill_block(blk, fft_len, ntaps, hist, x, n, out0);
+        ols_fill_block(blk, fft_len, ntaps, hop, hist, x, n, out0);
         ols_block(plan, Hf, fft_len, blk);
         size_t cnt = (n - out0 < hop) ? n - out0 : hop;
         memcpy(y + out0, blk + (ntaps - 1), cnt * sizeof(orc_cf32));
@@ -312,7 +315,7 @@ static void *ols_worker(void *arg)
     orc_cf32 *blk = (orc_cf32 *)malloc(j->fft_len * sizeof(orc_cf32));
     for (size_t b = j->blk0; b < j->blk1; b++) {
         size_t out0 = b * j->hop;
-        ols_fill_block(blk, j->fft_len, j->ntaps, NULL, j->x, j->n, out0);
+        ols_fill_block(blk, j->fft_len, j->ntaps, j->hop, NULL, j->x, j->n, out0);
         ols_block(plan, Hf, j->fft_len, blk);
         size_t cnt = (j->n - out0 < j->hop) ? j->n - out0 : j->hop;
         memcpy(j->y + out0, blk + (j->ntaps - 1), cnt * sizeof(orc_cf32));

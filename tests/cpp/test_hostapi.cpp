@@ -1,0 +1,126 @@
+// C++ host-API test: the reference's own unit tests and doctests, replayed through
+// include/aether_hip.hpp (the C++ mirror of trait VecOps / trait Fft) on the GPU.
+// Each block cites the reference test it restates.  Exit code 0 = all passed.
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/aether_hip.hpp"
+
+using namespace aether;
+static int failures = 0;
+#define RUN(name, ...)                                                          \
+    do {                                                                        \
+        try { __VA_ARGS__; std::printf("ok   %s\n", name); }                    \
+        catch (const std::exception &e) { failures++; std::printf("FAIL %s: %s\n", name, e.what()); } \
+    } while (0)
+#define EXPECT_PANIC(name, msg, ...)                                            \
+    do {                                                                        \
+        bool got = false;                                                       \
+        try { __VA_ARGS__; } catch (const Panic &p) { got = std::strstr(p.what(), msg) != nullptr; } \
+        if (got) std::printf("ok   %s\n", name); else { failures++; std::printf("FAIL %s: expected panic '%s'\n", name, msg); } \
+    } while (0)
+
+int main()
+{
+    Context ctx(0);
+    auto vec = [](size_t n, float re, float im) { return std::vector<cf32>(n, cf32(re, im)); };
+
+    // src/vecops.rs:339-424 -- one test per op, device-resident receiver
+    RUN("vec_scale", { DeviceVec v(ctx, vec(100, .5f, .5f)); v.vec_scale(2.0f); assert_evm(v.to_host(), vec(100, 1, 1)); });
+    RUN("vec_mul", { DeviceVec a(ctx, vec(100, 1, 1)), b(ctx, vec(100, 0, 2)); a.vec_mul(b); assert_evm(a.to_host(), vec(100, -2, 2)); });
+    RUN("vec_div", { DeviceVec a(ctx, vec(100, 2, 2)), b(ctx, vec(100, 2, 0)); a.vec_div(b); assert_evm(a.to_host(), vec(100, 1, 1)); });
+    RUN("vec_conj", { DeviceVec a(ctx, vec(100, 1, 1)); a.vec_conj(); assert_evm(a.to_host(), vec(100, 1, -1)); });
+    RUN("vec_add", { DeviceVec a(ctx, vec(100, 1, 1)), b(ctx, vec(100, 1, 1)); a.vec_add(b); assert_evm(a.to_host(), vec(100, 2, 2)); });
+    RUN("vec_sub", { DeviceVec a(ctx, vec(100, 2, 2)), b(ctx, vec(100, 1, 1)); a.vec_sub(b); assert_evm(a.to_host(), vec(100, 1, 1)); });
+    RUN("vec_mirror", {
+        std::vector<cf32> e = {{0, 0}, {1, 0}, {2, 0}, {3, 0}};
+        DeviceVec a(ctx, e); a.vec_mirror();
+        assert_evm(a.to_host(), std::vector<cf32>{{2, 0}, {3, 0}, {0, 0}, {1, 0}});
+    });
+    RUN("vec_clone", { DeviceVec a(ctx, vec(100, 2, 2)), b(ctx, vec(100, 1, 1)); a.vec_clone(b); assert_evm(a.to_host(), vec(100, 1, 1)); });
+    RUN("vec_zero", { DeviceVec a(ctx, vec(100, 2, 2)); a.vec_zero(); assert_evm(a.to_host(), vec(100, 0, 0)); });
+    // src/vecops.rs:426-441 -- stateful closure
+    RUN("vec_mutate", {
+        DeviceVec a(ctx, vec(100, 1, 1)); int x = 0;
+        a.vec_mutate([&](cf32 &c) { c *= (float)x; x++; });
+        std::vector<cf32> lin(100); for (int i = 0; i < 100; i++) lin[i] = cf32((float)i, (float)i);
+        assert_evm(a.to_host(), lin);
+    });
+    // src/vecops.rs:12-38 -- the chained doctest
+    RUN("vecops doctest chain", {
+        DeviceVec v(ctx, vec(100, 2, 2)), twos(ctx, vec(100, 2, 2)), ones(ctx, vec(100, 1, 1));
+        v.vec_div(twos).vec_mul(twos).vec_zero().vec_add(ones).vec_sub(twos).vec_clone(ones)
+            .vec_mutate([](cf32 &c) { c.imag(-1.0f); }).vec_conj().vec_mirror();
+        assert_evm(v.to_host(), vec(100, 1, 1), -80.0);
+    });
+    // the same chain on a host slice (the literal `impl VecOps for Vec<cf32>`)
+    RUN("vecops doctest chain (host slice)", {
+        auto v = vec(100, 2, 2); auto twos = v; auto ones = vec(100, 1, 1);
+        HostVec(ctx, v).vec_div(twos).vec_mul(twos).vec_zero().vec_add(ones).vec_sub(twos).vec_clone(ones)
+            .vec_mutate([](cf32 &c) { c.imag(-1.0f); }).vec_conj().vec_mirror();
+        assert_evm(v, ones, -80.0);
+    });
+    EXPECT_PANIC("vec_mul length assert", "Vectors must have same length",
+                 { DeviceVec a(ctx, vec(10, 1, 1)), b(ctx, vec(9, 1, 1)); a.vec_mul(b); });
+
+    // src/fft.rs:243-269 -- Scale
+    RUN("scale", {
+        if (Scale::SN().factor(4) != 0.5f || Scale::N().factor(4) != 0.25f || Scale::X(2).factor(4) != 2.0f ||
+            Scale::None().factor(4) != 1.0f) throw Panic(0, "scale factors");
+    });
+    // src/fft.rs:85-120 -- the Cfft doctest through the trait object
+    RUN("fft doctest (128 ones)", {
+        auto data = vec(128, 1, 0);
+        HostVec(ctx, data).vec_fft(Scale::None());
+        auto right = vec(128, 0, 0); right[0] = cf32(128, 0);
+        assert_evm(data, right);                                   // off-DC bins exactly zero
+        HipFft f = HipFft::with_len(ctx, 128);
+        Fft &dyn = f;
+        dyn.ibwd(data.data(), data.size(), Scale::N());
+        assert_evm(data, vec(128, 1, 0));
+        HostVec(ctx, data).vec_rfft(f, Scale::SN()).vec_scale(2.0f).vec_rifft(f, Scale::SN());
+        assert_evm(data, vec(128, 2, 0), -72);
+        if (dyn.len() != 128) throw Panic(0, "len");
+    });
+    // src/vecops.rs:443-463 -- round trips at N = 100
+    RUN("vec_fft / vec_rfft round trip N=100", {
+        auto v = vec(100, 1, 1);
+        DeviceVec c(ctx, v); c.vec_fft(Scale::SN()).vec_ifft(Scale::SN()); assert_evm(c.to_host(), v);
+        DeviceVec d(ctx, v); HipFft f(ctx, 100); d.vec_rfft(f, Scale::SN()).vec_rifft(f, Scale::SN()); assert_evm(d.to_host(), v);
+    });
+    RUN("tfwd lends the plan's temp", {
+        auto x = vec(64, 1, 0); HipFft f(ctx, 64);
+        const cf32 *t = f.tfwd(x.data(), x.size(), Scale::None());
+        if (t[0] != cf32(64, 0) || t[1] != cf32(0, 0)) throw Panic(0, "tfwd values");
+    });
+    EXPECT_PANIC("fft length assert", "Input and FFT must be the same length",
+                 { HipFft f(ctx, 128); auto x = vec(127, 1, 0); f.ifwd(x.data(), x.size(), Scale::None()); });
+
+    // src/sampling.rs:72-169
+    RUN("interpolate 2 between (appends)", {
+        std::vector<cf32> src = {{0, 0}, {3, 3}, {6, 6}, {9, 9}}, dst = {{7, 7}};
+        interpolate(ctx, src, dst, 2);
+        if (dst.size() != 11) throw Panic(0, "len");
+        for (int i = 0; i < 10; i++) if (dst[i + 1] != cf32((float)i, (float)i)) throw Panic(0, "value");
+    });
+    RUN("downsample 21 -> 7 (generic T)", {
+        std::vector<int> src(21), dst(7); for (int i = 0; i < 21; i++) src[i] = i;
+        downsample(ctx, src, dst);
+        for (int i = 0; i < 7; i++) if (dst[i] != 3 * i) throw Panic(0, "value");
+        downsample_sb(ctx, src, dst);
+    });
+    EXPECT_PANIC("downsample 7 -> 3", "Only even decimations are supported",
+                 { std::vector<int> s(7), d(3); downsample(ctx, s, d); });
+
+    // FIR: impulse in, taps out
+    RUN("fir impulse response", {
+        std::vector<cf32> taps(64); for (int k = 0; k < 64; k++) taps[k] = cf32(1.0f / (k + 1), 0.01f * k);
+        std::vector<cf32> x(5000, cf32(0, 0)), y; x[0] = cf32(1, 0);
+        Fir fir(ctx, taps, 2048); fir.filter(x, y);
+        for (int k = 0; k < 64; k++) if (std::abs(y[k] - taps[k]) > 1e-6f) throw Panic(0, "taps");
+        for (int k = 64; k < 5000; k++) if (std::abs(y[k]) > 1e-6f) throw Panic(0, "tail");
+    });
+
+    std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "PASSED", failures, failures == 1 ? "" : "s");
+    return failures ? 1 : 0;
+}

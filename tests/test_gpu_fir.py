@@ -86,6 +86,23 @@ def test_history_continues_a_stream(ctx, oracle, taps):
     assert oracle.evm_db(nohist[:63], whole[cut:cut + 63]) > -40
 
 
+def test_hop_aligned_shards_are_bit_identical(ctx, taps):
+    """shard boundaries aligned to the hop + (ntaps-1)-sample history read from the
+    source => every shard runs exactly the blocks of the 1-GPU run => identical bits for any G."""
+    from aether_primitives_amd.sharding import fir_shard
+    n = 300000
+    x = rand_c64(11, n)
+    f = Fir(ctx, taps, 2048)
+    whole = f.filter(ctx.vec(x)).to_host()
+    for world in (2, 3, 8):
+        parts = []
+        for r in range(world):
+            s = fir_shard(n, f.hop, f.ntaps, r, world)
+            hist = ctx.vec(x[s["hist_lo"]:s["in_lo"]]) if s["in_lo"] else None
+            parts.append(f.filter(ctx.vec(x[s["in_lo"]:s["out_hi"]]), hist=hist).to_host())
+        assert bits_equal(np.concatenate(parts), whole), world
+
+
 def test_fir_is_linear_and_shift_invariant(ctx, oracle, taps):
     f = Fir(ctx, taps, 2048)
     x, z = rand_c64(2, 40000), rand_c64(3, 40000)
