@@ -1,0 +1,74 @@
+//! `extern "C"` declarations: one to one with include/aether_hip.h.
+#![allow(non_camel_case_types)]
+use aether_primitives::cf32;
+use std::os::raw::{c_char, c_float, c_int, c_void};
+
+#[repr(C)] pub struct aeth_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct aeth_fft { _p: [u8; 0] }
+#[repr(C)] pub struct aeth_fir { _p: [u8; 0] }
+
+pub const AETH_OK: c_int = 0;
+pub const AETH_E_LEN: c_int = -1;
+pub const AETH_SCALE_NONE: c_int = 0;
+pub const AETH_SCALE_SN: c_int = 1;
+pub const AETH_SCALE_N: c_int = 2;
+pub const AETH_SCALE_X: c_int = 3;
+/// The ONE place where the reference's method names meet an exponent sign:
+/// `Cfft::with_len` plans `fwd` with `FFTplanner::new(true)` (rustfft "inverse", +j)
+/// and `bwd` with `FFTplanner::new(false)` (src/fft.rs:148,150).
+pub const AETH_SIGN_REF_FWD: c_int = 1;
+pub const AETH_SIGN_REF_BWD: c_int = -1;
+
+// cf32 = Complex<f32> is repr(C) {re, im} (src/lib.rs:8-12) == aeth_cf32
+extern "C" {
+    pub fn aeth_last_error() -> *const c_char;
+    pub fn aeth_ctx_create(device: c_int, out: *mut *mut aeth_ctx) -> c_int;
+    pub fn aeth_ctx_destroy(ctx: *mut aeth_ctx) -> c_int;
+    pub fn aeth_ctx_sync(ctx: *mut aeth_ctx) -> c_int;
+    pub fn aeth_dev_alloc(ctx: *mut aeth_ctx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
+    pub fn aeth_dev_free(ctx: *mut aeth_ctx, dptr: *mut c_void) -> c_int;
+    pub fn aeth_upload(ctx: *mut aeth_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn aeth_download(ctx: *mut aeth_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+
+    pub fn aeth_vec_scale(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, scale: c_float) -> c_int;
+    pub fn aeth_vec_mul(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_vec_div(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_vec_conj(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
+    pub fn aeth_vec_add(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_vec_sub(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_vec_mirror(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
+    pub fn aeth_vec_clone(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_vec_zero(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
+
+    pub fn aeth_fft_create(ctx: *mut aeth_ctx, len: usize, max_batch: usize, out: *mut *mut aeth_fft) -> c_int;
+    pub fn aeth_fft_destroy(plan: *mut aeth_fft) -> c_int;
+    pub fn aeth_fft_len(plan: *const aeth_fft) -> usize;
+    pub fn aeth_fft_exec(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, batch: usize,
+                         sign: c_int, scale_kind: c_int, x: c_float) -> c_int;
+    pub fn aeth_fft_exec_host(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, n_out: usize,
+                              sign: c_int, scale_kind: c_int, x: c_float) -> c_int;
+    pub fn aeth_fft_exec_tmp_host(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, sign: c_int,
+                                  scale_kind: c_int, x: c_float, view: *mut *const cf32) -> c_int;
+    pub fn aeth_fft_mul_ifft(plan: *mut aeth_fft, frames: *mut cf32, n_total: usize, batch: usize,
+                             sig: *const cf32, n_sig: usize, kf: c_int, xf: c_float, kb: c_int, xb: c_float) -> c_int;
+
+    pub fn aeth_fir_create(ctx: *mut aeth_ctx, taps: *const cf32, ntaps: usize, fft_len: usize,
+                           out: *mut *mut aeth_fir) -> c_int;
+    pub fn aeth_fir_destroy(fir: *mut aeth_fir) -> c_int;
+    pub fn aeth_fir_exec(fir: *mut aeth_fir, hist: *const cf32, inp: *const cf32, n: usize, out: *mut cf32) -> c_int;
+    pub fn aeth_fir_exec_host(fir: *mut aeth_fir, hist: *const cf32, inp: *const cf32, n: usize, out: *mut cf32) -> c_int;
+
+    pub fn aeth_host_interpolate(ctx: *mut aeth_ctx, src: *const cf32, n_src: usize, dst: *mut cf32, cap: usize,
+                                 n_between: usize, compat_im: c_int, n_written: *mut usize) -> c_int;
+    pub fn aeth_host_downsample(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void,
+                                n_dst: usize, elem_size: usize) -> c_int;
+}
+
+/// Error convention: the reference panics (assert_eq!); the C ABI returns a code and a
+/// thread-local message that carries the reference's panic text verbatim.
+pub fn check(rc: c_int) {
+    if rc != AETH_OK {
+        let msg = unsafe { std::ffi::CStr::from_ptr(aeth_last_error()) }.to_string_lossy().into_owned();
+        panic!("{}", msg);
+    }
+}

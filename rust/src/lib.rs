@@ -1,0 +1,146 @@
+//! aether_hip -- MI355X backend behind aether_primitives' own traits.
+//!
+//! * `HipFft` implements `aether_primitives::fft::Fft` (src/fft.rs:48-77), so it plugs
+//!   into `vec_rfft` / `vec_rifft` (generic over `impl Fft`, src/vecops.rs:83,88) exactly
+//!   where `Cfft` does: `data.vec_rfft(&mut hip_fft, Scale::SN)`.
+//! * `DeviceVec` keeps samples in HBM and offers the `VecOps` method set with the same
+//!   names and chaining (`&mut self -> &mut Self`), one kernel launch per call.
+//! * `sampling::{interpolate, downsample}` have the reference's signatures.
+//!
+//! Not compiled in this pipeline (no Rust toolchain): see Cargo.toml.
+pub mod ffi;
+
+use aether_primitives::cf32;
+use aether_primitives::fft::{Fft, Scale};
+use ffi::*;
+use std::os::raw::c_void;
+use std::ptr;
+
+fn scale_args(s: Scale) -> (i32, f32) {
+    match s {
+        Scale::None => (AETH_SCALE_NONE, 0.0),
+        Scale::SN => (AETH_SCALE_SN, 0.0),
+        Scale::N => (AETH_SCALE_N, 0.0),
+        Scale::X(x) => (AETH_SCALE_X, x),
+    }
+}
+
+/// One device + one HIP stream.  `Send` (may move between pipeline threads like a
+/// pooled `Cfft`, src/pool.rs:69-71), not `Sync` (every method takes `&mut self`).
+pub struct Context { h: *mut aeth_ctx }
+unsafe impl Send for Context {}
+impl Context {
+    pub fn new(device: i32) -> Context {
+        let mut h = ptr::null_mut();
+        check(unsafe { aeth_ctx_create(device, &mut h) });
+        Context { h }
+    }
+    pub fn sync(&mut self) { check(unsafe { aeth_ctx_sync(self.h) }) }
+}
+impl Drop for Context { fn drop(&mut self) { unsafe { aeth_ctx_destroy(self.h); } } }
+
+/// Replaces `Cfft` (src/fft.rs:134-235).
+pub struct HipFft { h: *mut aeth_fft }
+unsafe impl Send for HipFft {}
+impl HipFft {
+    /// `Cfft::with_len` (src/fft.rs:147)
+    pub fn with_len(ctx: &mut Context, len: usize) -> HipFft {
+        let mut h = ptr::null_mut();
+        check(unsafe { aeth_fft_create(ctx.h, len, 1, &mut h) });
+        HipFft { h }
+    }
+    fn host(&mut self, input: &[cf32], output: *mut cf32, n_out: usize, sign: i32, s: Scale) {
+        let (k, x) = scale_args(s);
+        check(unsafe { aeth_fft_exec_host(self.h, input.as_ptr(), input.len(), output, n_out, sign, k, x) });
+    }
+    fn tmp(&mut self, input: &[cf32], sign: i32, s: Scale) -> &[cf32] {
+        let (k, x) = scale_args(s);
+        let mut view: *const cf32 = ptr::null();
+        check(unsafe { aeth_fft_exec_tmp_host(self.h, input.as_ptr(), input.len(), sign, k, x, &mut view) });
+        // borrow tied to &mut self: valid until the next call on this plan (src/fft.rs:68,73)
+        unsafe { std::slice::from_raw_parts(view, self.len()) }
+    }
+}
+impl Drop for HipFft { fn drop(&mut self) { unsafe { aeth_fft_destroy(self.h); } } }
+
+impl Fft for HipFft {
+    fn fwd(&mut self, input: &[cf32], output: &mut [cf32], s: Scale) {
+        self.host(input, output.as_mut_ptr(), output.len(), AETH_SIGN_REF_FWD, s)
+    }
+    fn bwd(&mut self, input: &[cf32], output: &mut [cf32], s: Scale) {
+        self.host(input, output.as_mut_ptr(), output.len(), AETH_SIGN_REF_BWD, s)
+    }
+    fn ifwd(&mut self, input: &mut [cf32], s: Scale) {
+        let (p, n) = (input.as_mut_ptr(), input.len());
+        self.host(unsafe { std::slice::from_raw_parts(p, n) }, p, n, AETH_SIGN_REF_FWD, s)
+    }
+    fn ibwd(&mut self, input: &mut [cf32], s: Scale) {
+        let (p, n) = (input.as_mut_ptr(), input.len());
+        self.host(unsafe { std::slice::from_raw_parts(p, n) }, p, n, AETH_SIGN_REF_BWD, s)
+    }
+    fn tfwd(&mut self, input: &[cf32], s: Scale) -> &[cf32] { self.tmp(input, AETH_SIGN_REF_FWD, s) }
+    fn tbwd(&mut self, input: &[cf32], s: Scale) -> &[cf32] { self.tmp(input, AETH_SIGN_REF_BWD, s) }
+    fn len(&self) -> usize { unsafe { aeth_fft_len(self.h) } }
+}
+
+/// Device-resident `[cf32]` with the `VecOps` method set (src/vecops.rs:39-89).
+pub struct DeviceVec<'c> { ctx: &'c mut Context, p: *mut cf32, n: usize }
+impl<'c> DeviceVec<'c> {
+    pub fn from_slice(ctx: &'c mut Context, host: &[cf32]) -> DeviceVec<'c> {
+        let mut p: *mut c_void = ptr::null_mut();
+        check(unsafe { aeth_dev_alloc(ctx.h, host.len() * 8, &mut p) });
+        check(unsafe { aeth_upload(ctx.h, p, host.as_ptr() as *const c_void, host.len() * 8) });
+        DeviceVec { ctx, p: p as *mut cf32, n: host.len() }
+    }
+    pub fn to_vec(&mut self) -> Vec<cf32> {
+        let mut v = vec![cf32::default(); self.n];
+        check(unsafe { aeth_download(self.ctx.h, v.as_mut_ptr() as *mut c_void, self.p as *const c_void, self.n * 8) });
+        v
+    }
+    pub fn len(&self) -> usize { self.n }
+    pub fn vec_scale(&mut self, s: f32) -> &mut Self { check(unsafe { aeth_vec_scale(self.ctx.h, self.p, self.n, s) }); self }
+    pub fn vec_mul(&mut self, o: &DeviceVec) -> &mut Self { check(unsafe { aeth_vec_mul(self.ctx.h, self.p, self.n, o.p, o.n) }); self }
+    pub fn vec_div(&mut self, o: &DeviceVec) -> &mut Self { check(unsafe { aeth_vec_div(self.ctx.h, self.p, self.n, o.p, o.n) }); self }
+    pub fn vec_conj(&mut self) -> &mut Self { check(unsafe { aeth_vec_conj(self.ctx.h, self.p, self.n) }); self }
+    pub fn vec_mirror(&mut self) -> &mut Self { check(unsafe { aeth_vec_mirror(self.ctx.h, self.p, self.n) }); self }
+    pub fn vec_clone(&mut self, o: &DeviceVec) -> &mut Self { check(unsafe { aeth_vec_clone(self.ctx.h, self.p, self.n, o.p, o.n) }); self }
+    pub fn vec_zero(&mut self) -> &mut Self { check(unsafe { aeth_vec_zero(self.ctx.h, self.p, self.n) }); self }
+    pub fn vec_add(&mut self, o: &DeviceVec) -> &mut Self { check(unsafe { aeth_vec_add(self.ctx.h, self.p, self.n, o.p, o.n) }); self }
+    pub fn vec_sub(&mut self, o: &DeviceVec) -> &mut Self { check(unsafe { aeth_vec_sub(self.ctx.h, self.p, self.n, o.p, o.n) }); self }
+    /// closures cannot cross the FFI: D2H, apply in order, H2D (slow by design)
+    pub fn vec_mutate(&mut self, f: impl FnMut(&mut cf32)) -> &mut Self {
+        let mut v = self.to_vec();
+        v.iter_mut().for_each(f);
+        check(unsafe { aeth_upload(self.ctx.h, self.p as *mut c_void, v.as_ptr() as *const c_void, self.n * 8) });
+        self
+    }
+    /// device frames through a plan: `len()` may be a multiple of `fft.len()` (a batch)
+    pub fn vec_rfft(&mut self, fft: &mut HipFft, s: Scale) -> &mut Self { self.exec(fft, AETH_SIGN_REF_FWD, s) }
+    pub fn vec_rifft(&mut self, fft: &mut HipFft, s: Scale) -> &mut Self { self.exec(fft, AETH_SIGN_REF_BWD, s) }
+    fn exec(&mut self, fft: &mut HipFft, sign: i32, s: Scale) -> &mut Self {
+        let (k, x) = scale_args(s);
+        let batch = if fft.len() > 0 { self.n / fft.len() } else { 0 };
+        check(unsafe { aeth_fft_exec(fft.h, self.p, self.n, self.p, batch, sign, k, x) });
+        self
+    }
+}
+impl<'c> Drop for DeviceVec<'c> { fn drop(&mut self) { unsafe { aeth_dev_free(self.ctx.h, self.p as *mut c_void); } } }
+
+pub mod sampling {
+    use super::*;
+    /// `sampling::interpolate` (src/sampling.rs:7-24): APPENDS to `dst`.
+    pub fn interpolate(ctx: &mut Context, src: &[cf32], dst: &mut Vec<cf32>, n_between: usize) {
+        assert!(!src.is_empty());                              // the reference unwrap()s src.last()
+        let add = src.len() + (src.len() - 1) * n_between;
+        dst.reserve(add);
+        let mut written = 0usize;
+        let tail = unsafe { dst.as_mut_ptr().add(dst.len()) };
+        check(unsafe { aeth_host_interpolate(ctx.h, src.as_ptr(), src.len(), tail, add, n_between, 1, &mut written) });
+        unsafe { dst.set_len(dst.len() + written) };
+    }
+    /// `sampling::downsample<T: Copy>` (src/sampling.rs:28-42)
+    pub fn downsample<T: Copy>(ctx: &mut Context, src: &[T], dst: &mut [T]) {
+        check(unsafe { aeth_host_downsample(ctx.h, src.as_ptr() as *const c_void, src.len(),
+                                            dst.as_mut_ptr() as *mut c_void, dst.len(), std::mem::size_of::<T>()) });
+    }
+}
