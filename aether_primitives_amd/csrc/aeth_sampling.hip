@@ -13,50 +13,58 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// frames of S inputs -> frames of Lo = S + (S-1)*nb outputs
-__global__ __launch_bounds__(kBlock) void interpolate_kernel(const float2 *__restrict__ src, float2 *__restrict__ dst,
-                                                             size_t S, size_t Lo, size_t batch, unsigned nb1,
-                                                             float div, int compat_im)
+// one interpolated output: window w, step i of frame f (sampling.rs:8-23)
+__device__ __forceinline__ float2 interp_at(const float2 *__restrict__ s, size_t S, size_t w, unsigned i, float div,
+                                            int compat_im)
 {
-    const size_t total = Lo * batch;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += stride) {
-        size_t f = o / Lo;
-        size_t j = o - f * Lo;                    // position inside the output frame
-        const float2 *s = src + f * S;
-        size_t w = j / nb1;                       // window index            (sampling.rs:8)
-        unsigned i = (unsigned)(j - w * nb1);     // 0..=n_between           (sampling.rs:16)
-        float2 out;
-        if (w >= S - 1) {
-            out = s[S - 1];                       // dst.push(*src.last())   (sampling.rs:23)
-        } else {
-            float2 x1 = s[w], x2 = s[w + 1];
-            float r0 = (x2.x - x1.x) / div;       // (sampling.rs:12)
-            float r1 = (x2.y - x1.y) / div;       // (sampling.rs:13)
-            float fi = (float)i;
-            out.x = x1.x + fi * r0;               // (sampling.rs:18)
-            out.y = (compat_im ? x1.x : x1.y) + fi * r1;   // (sampling.rs:19, sic)
-        }
-        dst[o] = out;
-    }
+    if (w >= S - 1) return s[S - 1];              // dst.push(*src.last())   (sampling.rs:23)
+    float2 x1 = s[w], x2 = s[w + 1];
+    float r0 = (x2.x - x1.x) / div;               // (sampling.rs:12)
+    float r1 = (x2.y - x1.y) / div;               // (sampling.rs:13)
+    float fi = (float)i;                          // (sampling.rs:16)
+    float2 out;
+    out.x = x1.x + fi * r0;                       // (sampling.rs:18)
+    out.y = (compat_im ? x1.x : x1.y) + fi * r1;  // (sampling.rs:19, sic)
+    return out;
+}
+
+// frames of S inputs -> frames of Lo = S + (S-1)*nb outputs.  Two consecutive outputs per
+// lane (one 16-byte store when the destination allows): the index of the second follows
+// from the first without another division.  IDX = uint32_t when everything fits 32 bits.
+template <typename IDX>
+__global__ __launch_bounds__(kBlock) void interpolate_kernel(const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                             IDX S, IDX Lo, IDX total, unsigned nb1, float div,
+                                                             int compat_im, int single_frame, int wide_store)
+{
+    const IDX o = ((IDX)blockIdx.x * kBlock + threadIdx.x) * 2;
+    if (o >= total) return;
+    IDX f = 0, j = o;
+    if (!single_frame) { f = o / Lo; j = o - f * Lo; }      // position inside the output frame
+    IDX w = j / nb1;                                        // window index  (sampling.rs:8)
+    unsigned i = (unsigned)(j - w * nb1);                   // 0..=n_between
+    const float2 v0 = interp_at(src + (size_t)f * S, S, w, i, div, compat_im);
+    if (o + 1 >= total) { dst[o] = v0; return; }
+    // next output: same window one step on, or the next window, or the next frame
+    if (++j == Lo) { j = 0; f++; w = 0; i = 0; }
+    else if (++i == nb1) { i = 0; w++; }
+    const float2 v1 = interp_at(src + (size_t)f * S, S, w, i, div, compat_im);
+    if (wide_store) *reinterpret_cast<float4 *>(dst + o) = make_float4(v0.x, v0.y, v1.x, v1.y);
+    else { dst[o] = v0; dst[o + 1] = v1; }
 }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void downsample_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                             size_t n_dst, size_t dec)
 {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_dst; i += stride)
-        dst[i] = src[i * dec];                    // *c = src[i * dec]       (sampling.rs:39-41)
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_dst) dst[i] = src[i * dec];         // *c = src[i * dec]       (sampling.rs:39-41)
 }
 
-inline int grid_for(const aeth_ctx *ctx, size_t items)
+// one item per lane, the grid covers everything (see aeth_vecops.hip on why no capped loop)
+inline unsigned grid_for(const aeth_ctx *, size_t items)
 {
     size_t blocks = (items + kBlock - 1) / kBlock;
-    size_t cap = (size_t)ctx->num_cus * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return (int)blocks;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
 }
 
 int interpolate_impl(aeth_ctx *ctx, const aeth_cf32 *src, size_t S, size_t batch, aeth_cf32 *dst,
@@ -71,9 +79,17 @@ int interpolate_impl(aeth_ctx *ctx, const aeth_cf32 *src, size_t S, size_t batch
     AETH_REQUIRE(aeth::aligned8(src) && aeth::aligned8(dst), AETH_E_ALIGN, "pointer not 8-byte aligned");
     const size_t Lo = S + (S - 1) * nb;
     AETH_REQUIRE(cap >= Lo * batch, AETH_E_LEN, "dst capacity %zu < %zu", cap, Lo * batch);
-    hipLaunchKernelGGL(interpolate_kernel, dim3(grid_for(ctx, Lo * batch)), dim3(kBlock), 0, ctx->stream,
-                       reinterpret_cast<const float2 *>(src), reinterpret_cast<float2 *>(dst), S, Lo, batch,
-                       (unsigned)(nb + 1), (float)(nb + 1), compat);
+    const size_t total = Lo * batch;
+    const int wide = aeth::aligned16(dst) ? 1 : 0;
+    const dim3 g(grid_for(ctx, (total + 1) / 2)), b(kBlock);
+    if (total < 0xffffffffull && S < 0xffffffffull)
+        hipLaunchKernelGGL(interpolate_kernel<uint32_t>, g, b, 0, ctx->stream, reinterpret_cast<const float2 *>(src),
+                           reinterpret_cast<float2 *>(dst), (uint32_t)S, (uint32_t)Lo, (uint32_t)total,
+                           (unsigned)(nb + 1), (float)(nb + 1), compat, batch == 1 ? 1 : 0, wide);
+    else
+        hipLaunchKernelGGL(interpolate_kernel<uint64_t>, g, b, 0, ctx->stream, reinterpret_cast<const float2 *>(src),
+                           reinterpret_cast<float2 *>(dst), (uint64_t)S, (uint64_t)Lo, (uint64_t)total,
+                           (unsigned)(nb + 1), (float)(nb + 1), compat, batch == 1 ? 1 : 0, wide);
     AETH_HIP(hipGetLastError());
     if (n_written) *n_written = Lo * batch;
     return AETH_OK;
