@@ -19,6 +19,7 @@
 #include "aeth_fft_plan.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 using namespace aeth::fftk;
@@ -28,11 +29,18 @@ namespace {
 // single LDS image regardless of size (the column/row kernels hold G frames per workgroup)
 template <class C> struct OneImage : C { static constexpr bool DB = false; };
 
+// LDS stride between the frames of a column group.  Adjacent LANES are adjacent COLUMNS
+// here, so the frame stride decides the banking: one exchange image is LDS_FRAME elements
+// (a multiple of 16 elements = 32 banks, which would put all 16 columns on two bank
+// positions: 8-way conflicts on every access); a stride of 1 element modulo 32 elements
+// makes the 16 lanes of a write group land on 16 consecutive 8-byte slots.
+template <class C> constexpr int col_stride() { return C::LDS_FRAME + ((33 - C::LDS_FRAME % 32) % 32); }
+
 template <class C> constexpr int group_of()
 {
     // frames per workgroup: 16 for 128-byte segments, fewer when lanes or LDS run out
     int g = 16;
-    while (g > 1 && (g * C::T > 1024 || g * C::LDS_FRAME * 8 > 64 * 1024)) g /= 2;
+    while (g > 1 && (g * C::T > 1024 || g * col_stride<C>() * 8 > 64 * 1024)) g /= 2;
     return g;
 }
 
@@ -44,7 +52,8 @@ __global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_cols(const cf
 {
     using C = OneImage<C0>;
     constexpr int G = group_of<C0>();
-    __shared__ cf lds_all[G * C::LDS_FRAME > 0 ? G * C::LDS_FRAME : 1];
+    constexpr int CS = col_stride<C0>();
+    __shared__ cf lds_all[G * CS > 0 ? G * CS : 1];
     const int col = threadIdx.x % G;
     const int tid = threadIdx.x / G;
     const int groups_per_frame = N2 / G;
@@ -57,13 +66,28 @@ __global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_cols(const cf
     cf w[C::P];
 #pragma unroll
     for (int m = 0; m < C::P; m++) w[m] = src[(size_t)(tid + m * C::T) * N2];
-    fft_in_regs<C, S, 0>(w, tw, lds_all + col * C::LDS_FRAME, tid);
+    fft_in_regs<C, S, 0>(w, tw, lds_all + col * CS, tid);
+    // twiddle W_N^(n2*k1), k1 = tid + m*T: a geometric sequence in m for this lane,
+    //   W_N^(n2*tid) * (W_N^(T*n2))^m.
+    // Three table reads (a, b, b^4) and short product chains (depth <= 5) replace one
+    // scattered 8-byte gather per element, which costs more than the arithmetic here.
+    if (twN) {
+        const cf a = twN[(size_t)n2 * tid];
+        const cf b1 = twN[(size_t)n2 * C::T];
+        const cf b4 = twN[(size_t)n2 * C::T * 4];
+        const cf b2 = cmul(b1, b1), b3 = cmul(b2, b1);
+        cf base = a;
 #pragma unroll
-    for (int m = 0; m < C::P; m++) {
-        const int k1 = tid + m * C::T;
-        cf t = twN[(size_t)n2 * k1];                       // W_N^(n2*k1), n2*k1 < N
-        dst[(size_t)k1 * N2] = ctw<S>(w[m], t);
+        for (int q = 0; q < C::P / 4; q++) {
+            w[4 * q + 0] = ctw<S>(w[4 * q + 0], base);
+            w[4 * q + 1] = ctw<S>(w[4 * q + 1], cmul(base, b1));
+            w[4 * q + 2] = ctw<S>(w[4 * q + 2], cmul(base, b2));
+            w[4 * q + 3] = ctw<S>(w[4 * q + 3], cmul(base, b3));
+            base = cmul(base, b4);
+        }
     }
+#pragma unroll
+    for (int m = 0; m < C::P; m++) dst[(size_t)(tid + m * C::T) * N2] = w[m];
 }
 
 // ---- step B: G rows per workgroup, transposed store --------------------------------
@@ -112,7 +136,7 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch)
     const size_t grid = batch * (plan->n2 / G);
     hipLaunchKernelGGL((fourstep_cols<C, S>), dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
                        (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
-                       (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
+                       getenv("AETH_4S_NOTW") ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
