@@ -13,43 +13,115 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// one interpolated output: window w, step i of frame f (sampling.rs:8-23)
-__device__ __forceinline__ float2 interp_at(const float2 *__restrict__ s, size_t S, size_t w, unsigned i, float div,
-                                            int compat_im)
+// Linear interpolation, frames of S inputs -> frames of Lo = S + (S-1)*nb outputs.
+//
+// A workgroup owns 512 consecutive outputs (two per lane, one 16-byte store when the
+// destination allows).  Phase 1: the few input windows those outputs fall into (about
+// 512/(nb+1)) get their per-window constants -- x1 and the two rates, i.e. the two f32
+// divisions of sampling.rs:12-13 -- computed ONCE into LDS.  Phase 2: every output is
+// one LDS read, a multiply and an add per component, in the reference's operation
+// order (sampling.rs:18-19), so results stay bit-identical while the divisions per
+// output drop from 2 to ~2/(nb+1).  Slots run on across frame boundaries; the last
+// sample of a frame is a pseudo-window with zero rates (sampling.rs:23).
+constexpr int kChunks = 4;                      // 16-byte stores per lane
+constexpr int kOutPerWG = 2 * kBlock * kChunks; // outputs per workgroup: amortises the load -> LDS -> store latency chain
+
+// n / d for 32-bit n by multiply-high and shifts (Granlund-Montgomery round-up form):
+// the index arithmetic of this store-bound kernel must not cost more than its stores.
+struct FastDiv {
+    uint32_t d, m, sh1, sh2;
+};
+inline FastDiv make_fastdiv(uint32_t d)
 {
-    if (w >= S - 1) return s[S - 1];              // dst.push(*src.last())   (sampling.rs:23)
-    float2 x1 = s[w], x2 = s[w + 1];
-    float r0 = (x2.x - x1.x) / div;               // (sampling.rs:12)
-    float r1 = (x2.y - x1.y) / div;               // (sampling.rs:13)
-    float fi = (float)i;                          // (sampling.rs:16)
-    float2 out;
-    out.x = x1.x + fi * r0;                       // (sampling.rs:18)
-    out.y = (compat_im ? x1.x : x1.y) + fi * r1;  // (sampling.rs:19, sic)
-    return out;
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f)
+{
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
-// frames of S inputs -> frames of Lo = S + (S-1)*nb outputs.  Two consecutive outputs per
-// lane (one 16-byte store when the destination allows): the index of the second follows
-// from the first without another division.  IDX = uint32_t when everything fits 32 bits.
-template <typename IDX>
-__global__ __launch_bounds__(kBlock) void interpolate_kernel(const float2 *__restrict__ src, float2 *__restrict__ dst,
-                                                             IDX S, IDX Lo, IDX total, unsigned nb1, float div,
-                                                             int compat_im, int single_frame, int wide_store)
+// 32-bit index version (total < 2^31): the common case
+__global__ __launch_bounds__(kBlock) void interpolate_kernel32(const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                               uint32_t S, FastDiv Lo, uint32_t total, FastDiv nb1,
+                                                               float div, int compat_im, int wide_store)
 {
-    const IDX o = ((IDX)blockIdx.x * kBlock + threadIdx.x) * 2;
+    extern __shared__ __attribute__((aligned(16))) float4 slot[];   // (x1.re, imaginary base, rate.0, rate.1), sized by the host
+    const uint32_t o0 = blockIdx.x * kOutPerWG;             // first output of this workgroup
+    const uint32_t f0 = fdiv(o0, Lo);
+    const uint32_t w0 = fdiv(o0 - f0 * Lo.d, nb1);          // its window (sampling.rs:8)
+    uint32_t olast = o0 + kOutPerWG - 1;
+    if (olast >= total) olast = total - 1;
+    const uint32_t fl = fdiv(olast, Lo);
+    const uint32_t wl = fdiv(olast - fl * Lo.d, nb1);
+    const uint32_t nslots = (fl - f0) * S + wl - w0 + 1;
+    for (uint32_t q = threadIdx.x; q < nslots; q += kBlock) {
+        uint32_t w = w0 + q, f = f0;
+        while (w >= S) { w -= S; f++; }                     // slots continue into the next frame
+        const float2 *s = src + (size_t)f * S;
+        const float2 x1 = s[w];
+        float4 e;
+        if (w == S - 1) e = make_float4(x1.x, x1.y, 0.0f, 0.0f);      // dst.push(*src.last())  (sampling.rs:23)
+        else {
+            const float2 x2 = s[w + 1];
+            e.x = x1.x;
+            e.y = compat_im ? x1.x : x1.y;                  // sampling.rs:19 uses x1.re (sic)
+            e.z = (x2.x - x1.x) / div;                      // sampling.rs:12
+            e.w = (x2.y - x1.y) / div;                      // sampling.rs:13
+        }
+        slot[q] = e;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kChunks; c++) {
+        const uint32_t o = o0 + c * (2 * kBlock) + 2 * threadIdx.x;
+        if (o >= total) return;
+        uint32_t f = fdiv(o, Lo), j = o - f * Lo.d;
+        uint32_t w = fdiv(j, nb1);
+        uint32_t i = j - w * nb1.d;                         // 0..=n_between (sampling.rs:16)
+        uint32_t q = (f - f0) * S + w - w0;
+        float4 e = slot[q];
+        float fi = (float)i;
+        const float2 v0 = make_float2(e.x + fi * e.z, e.y + fi * e.w);    // sampling.rs:18-19
+        if (o + 1 >= total) { dst[o] = v0; return; }
+        if (j + 1 == Lo.d) { q = (f + 1 - f0) * S - w0; i = 0; }          // first output of the next frame
+        else if (++i == nb1.d) { i = 0; q++; }
+        e = slot[q];
+        fi = (float)i;
+        const float2 v1 = make_float2(e.x + fi * e.z, e.y + fi * e.w);
+        if (wide_store) *reinterpret_cast<float4 *>(dst + o) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        else { dst[o] = v0; dst[o + 1] = v1; }
+    }
+}
+
+// 64-bit fallback (more than 2^31 outputs): one lane per output, plain division
+__global__ __launch_bounds__(kBlock) void interpolate_kernel64(const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                               size_t S, size_t Lo, size_t total, unsigned nb1,
+                                                               float div, int compat_im)
+{
+    const size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (o >= total) return;
-    IDX f = 0, j = o;
-    if (!single_frame) { f = o / Lo; j = o - f * Lo; }      // position inside the output frame
-    IDX w = j / nb1;                                        // window index  (sampling.rs:8)
-    unsigned i = (unsigned)(j - w * nb1);                   // 0..=n_between
-    const float2 v0 = interp_at(src + (size_t)f * S, S, w, i, div, compat_im);
-    if (o + 1 >= total) { dst[o] = v0; return; }
-    // next output: same window one step on, or the next window, or the next frame
-    if (++j == Lo) { j = 0; f++; w = 0; i = 0; }
-    else if (++i == nb1) { i = 0; w++; }
-    const float2 v1 = interp_at(src + (size_t)f * S, S, w, i, div, compat_im);
-    if (wide_store) *reinterpret_cast<float4 *>(dst + o) = make_float4(v0.x, v0.y, v1.x, v1.y);
-    else { dst[o] = v0; dst[o + 1] = v1; }
+    const size_t f = o / Lo, j = o - f * Lo;
+    const float2 *s = src + f * S;
+    const size_t w = j / nb1;
+    const unsigned i = (unsigned)(j - w * nb1);
+    float2 out;
+    if (w >= S - 1) out = s[S - 1];
+    else {
+        const float2 x1 = s[w], x2 = s[w + 1];
+        const float r0 = (x2.x - x1.x) / div, r1 = (x2.y - x1.y) / div;
+        const float fi = (float)i;
+        out.x = x1.x + fi * r0;
+        out.y = (compat_im ? x1.x : x1.y) + fi * r1;
+    }
+    dst[o] = out;
 }
 
 template <typename T>
@@ -81,15 +153,20 @@ int interpolate_impl(aeth_ctx *ctx, const aeth_cf32 *src, size_t S, size_t batch
     AETH_REQUIRE(cap >= Lo * batch, AETH_E_LEN, "dst capacity %zu < %zu", cap, Lo * batch);
     const size_t total = Lo * batch;
     const int wide = aeth::aligned16(dst) ? 1 : 0;
-    const dim3 g(grid_for(ctx, (total + 1) / 2)), b(kBlock);
-    if (total < 0xffffffffull && S < 0xffffffffull)
-        hipLaunchKernelGGL(interpolate_kernel<uint32_t>, g, b, 0, ctx->stream, reinterpret_cast<const float2 *>(src),
-                           reinterpret_cast<float2 *>(dst), (uint32_t)S, (uint32_t)Lo, (uint32_t)total,
-                           (unsigned)(nb + 1), (float)(nb + 1), compat, batch == 1 ? 1 : 0, wide);
-    else
-        hipLaunchKernelGGL(interpolate_kernel<uint64_t>, g, b, 0, ctx->stream, reinterpret_cast<const float2 *>(src),
-                           reinterpret_cast<float2 *>(dst), (uint64_t)S, (uint64_t)Lo, (uint64_t)total,
-                           (unsigned)(nb + 1), (float)(nb + 1), compat, batch == 1 ? 1 : 0, wide);
+    if (total < 0x7fffffffull && S < 0x7fffffffull) {
+        const dim3 g((unsigned)((total + kOutPerWG - 1) / kOutPerWG)), b(kBlock);
+        // slots a workgroup can need: one per window its outputs touch, plus the pseudo-window
+        // and a partial window per frame boundary it crosses
+        size_t slots = kOutPerWG / (nb + 1) + 2 * (kOutPerWG / Lo + 2) + 4;
+        if (slots > (size_t)kOutPerWG + 4) slots = kOutPerWG + 4;
+        hipLaunchKernelGGL(interpolate_kernel32, g, b, slots * sizeof(float4), ctx->stream, reinterpret_cast<const float2 *>(src),
+                           reinterpret_cast<float2 *>(dst), (uint32_t)S, make_fastdiv((uint32_t)Lo), (uint32_t)total,
+                           make_fastdiv((uint32_t)(nb + 1)), (float)(nb + 1), compat, wide);
+    } else {
+        hipLaunchKernelGGL(interpolate_kernel64, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream,
+                           reinterpret_cast<const float2 *>(src), reinterpret_cast<float2 *>(dst), S, Lo, total,
+                           (unsigned)(nb + 1), (float)(nb + 1), compat);
+    }
     AETH_HIP(hipGetLastError());
     if (n_written) *n_written = Lo * batch;
     return AETH_OK;
