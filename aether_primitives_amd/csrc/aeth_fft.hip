@@ -177,26 +177,34 @@ __device__ __forceinline__ void bfly7(cf (&u)[7], const cf *__restrict__ twN, in
 template <bool SWAP>
 __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *out,
                                                               const cf *__restrict__ twN, MixedDesc d,
-                                                              size_t batch, float scale)
+                                                              size_t batch, float scale, int tpf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *bufA = reinterpret_cast<cf *>(smem_raw);
-    cf *bufB = bufA + d.n;
+    // tpf lanes per frame, kMixedWG / tpf frames per workgroup (small lengths would leave
+    // most of a 256-lane workgroup idle: N = 100 has 25 radix-4 butterflies per pass)
     const int n = d.n;
-    for (size_t frame = blockIdx.x; frame < batch; frame += gridDim.x) {
+    const int fpw = kMixedWG / tpf;
+    const int fl = threadIdx.x / tpf;
+    const int lane = threadIdx.x % tpf;
+    cf *bufA = reinterpret_cast<cf *>(smem_raw) + (size_t)fl * 2 * n;
+    cf *bufB = bufA + n;
+    const size_t ngroups = (batch + fpw - 1) / fpw;
+    for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const size_t frame = grp * fpw + fl;
+        const bool active = frame < batch;
         const cf *gin = in + frame * (size_t)n;
         cf *gout = out + frame * (size_t)n;
         // stage the frame (lets every pass read LDS; keeps in-place launches safe)
         __syncthreads();
-        for (int e = threadIdx.x; e < n; e += kMixedWG) {
-            cf v = gin[e];
+        for (int e = lane; e < n; e += tpf) {
+            cf v = active ? gin[e] : mk(0.f, 0.f);
             bufA[e] = SWAP ? cswap(v) : v;
         }
         __syncthreads();
         if (d.nfac == 0) {      // len == 1: the DFT is the identity
-            for (int e = threadIdx.x; e < n; e += kMixedWG) {
+            for (int e = lane; e < n; e += tpf) {
                 cf v = cscale(bufA[e], scale);
-                gout[e] = SWAP ? cswap(v) : v;
+                if (active) gout[e] = SWAP ? cswap(v) : v;
             }
             continue;
         }
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
             const int m = n / R;
             const int step = n / (p * R);
             const bool last = (s == d.nfac - 1);
-            for (int i = threadIdx.x; i < m; i += kMixedWG) {
+            for (int i = lane; i < m; i += tpf) {
                 const int k = i % p;
                 const int j = (i - k) * R + k;
                 auto ld = [&](int r) -> cf {
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
                 auto st = [&](int r, cf v) {
                     if (last) {
                         v = cscale(v, scale);
-                        gout[j + r * p] = SWAP ? cswap(v) : v;
+                        if (active) gout[j + r * p] = SWAP ? cswap(v) : v;
                     } else Y[j + r * p] = v;
                 };
                 if (R == 2) {
@@ -274,14 +282,23 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
     d.n = (int)plan->len;
     d.nfac = (int)plan->factors.size();
     for (int i = 0; i < d.nfac; i++) d.fac[i] = plan->factors[i];
-    size_t cap = (size_t)ctx->num_cus * 4;
-    int grid = (int)(batch < cap ? batch : cap);
+    // lanes per frame: the widest pass (N / smallest radix butterflies), rounded up to a power of two
+    int minr = d.nfac ? d.fac[0] : 1;
+    for (int i = 1; i < d.nfac; i++) if (d.fac[i] < minr) minr = d.fac[i];
+    int need = d.nfac ? (d.n + minr - 1) / minr : d.n, tpf = 1;
+    while (tpf < need && tpf < kMixedWG) tpf <<= 1;
+    // two LDS images per frame; keep a workgroup under 64 KiB
+    while (tpf < kMixedWG && (size_t)(kMixedWG / tpf) * 2 * plan->len * sizeof(cf) > 64 * 1024) tpf <<= 1;
+    const int fpw = kMixedWG / tpf;
+    const size_t ngroups = (batch + fpw - 1) / fpw;
+    size_t cap = (size_t)ctx->num_cus * 8;
+    int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
-    const size_t shmem = 2 * plan->len * sizeof(cf);
+    const size_t shmem = (size_t)fpw * 2 * plan->len * sizeof(cf);
     if (sign > 0)
-        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale);
+        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale, tpf);
     else
-        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale);
+        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale, tpf);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
