@@ -16,7 +16,8 @@ from .context import Context, DeviceVec, HostVec          # noqa: E402
 from .fft import Scale, HipFft, SIGN_REF_FWD, SIGN_REF_BWD  # noqa: E402
 from .fir import Fir                                      # noqa: E402
 from . import sampling                                    # noqa: E402
+from . import modulation                                  # noqa: E402
 from .evm import assert_evm, evm_db                       # noqa: E402
 
 __all__ = ["AetherError", "LengthMismatch", "Context", "DeviceVec", "HostVec", "Scale", "HipFft",
-           "SIGN_REF_FWD", "SIGN_REF_BWD", "Fir", "sampling", "assert_evm", "evm_db"]
+           "SIGN_REF_FWD", "SIGN_REF_BWD", "Fir", "sampling", "modulation", "assert_evm", "evm_db"]

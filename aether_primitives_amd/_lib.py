@@ -81,6 +81,8 @@ PROTOTYPES = {
     "aeth_host_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),
     "aeth_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
     "aeth_host_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
+    "aeth_modulate": (i32, [vp, vp, sz, i32, vp, vp, sz]),
+    "aeth_demod_naive": (i32, [vp, vp, sz, i32, vp, vp, sz, i32]),
 }
 
 _lib = None

@@ -1,0 +1,85 @@
+"""trait Modulation for the generic BPSK / QPSK tables (reference: src/modulation.rs:5-149),
+device-resident.  Bits are one byte per bit, as in the reference."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .context import DeviceVec
+
+GENERIC_BPSK_TABLE = np.array([1 + 1j, -1 - 1j], np.complex64)                    # modulation.rs:77
+GENERIC_QPSK_TABLE = np.array([1 + 1j, -1 + 1j, 1 - 1j, -1 - 1j], np.complex64)   # modulation.rs:87-92
+
+
+class DeviceBits:
+    """u8-per-bit buffer in HBM."""
+
+    def __init__(self, ctx, n, host=None):
+        self.ctx, self.n = ctx, int(n)
+        self.ptr = ctx.alloc(max(self.n, 1))
+        if host is not None:
+            ctx.upload(self.ptr, np.ascontiguousarray(host, np.uint8))
+
+    def to_host(self):
+        out = np.empty(self.n, np.uint8)
+        if self.n:
+            self.ctx.download(self.ptr, out)
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.h:
+                self.ctx.free(self.ptr); self.ptr = None
+        except Exception:
+            pass
+
+
+class _Modulation:
+    BITS_PER_SYMBOL = 0
+    table = None
+
+    def __init__(self, ctx, table=None):
+        self.ctx = ctx
+        self._lib = _lib.load()
+        if table is not None:
+            self.table = np.ascontiguousarray(table, np.complex64)
+
+    def bits_per_symbol(self):                                  # modulation.rs:146-148
+        return self.BITS_PER_SYMBOL
+
+    def symbol(self, idx):                                      # modulation.rs:13-15 / :26-28
+        return self.table[idx]
+
+    def modulate(self, bits):                                   # modulation.rs:115-121
+        if not isinstance(bits, DeviceBits):
+            bits = DeviceBits(self.ctx, len(bits), bits)
+        out = DeviceVec(self.ctx, bits.n // self.BITS_PER_SYMBOL)
+        check(self._lib.aeth_modulate(self.ctx.h, C.c_void_p(bits.ptr), bits.n, self.BITS_PER_SYMBOL,
+                                      self.table.ctypes.data_as(C.c_void_p), out._p(), out.n))
+        return out
+
+    def demod_naive(self, symbols, compat=True):                # modulation.rs:33-56 / :133-144
+        out = DeviceBits(self.ctx, symbols.n * self.BITS_PER_SYMBOL)
+        check(self._lib.aeth_demod_naive(self.ctx.h, symbols._p(), symbols.n, self.BITS_PER_SYMBOL,
+                                         self.table.ctypes.data_as(C.c_void_p), C.c_void_p(out.ptr), out.n,
+                                         1 if compat else 0))
+        return out
+
+
+class Bpsk(_Modulation):
+    BITS_PER_SYMBOL = 1
+    table = GENERIC_BPSK_TABLE
+
+
+class Qpsk(_Modulation):
+    BITS_PER_SYMBOL = 2
+    table = GENERIC_QPSK_TABLE
+
+
+def bpsk(ctx):                                                  # modulation.rs:61-63
+    return Bpsk(ctx)
+
+
+def qpsk(ctx):                                                  # modulation.rs:66-68
+    return Qpsk(ctx)

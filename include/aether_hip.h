@@ -205,6 +205,22 @@ AETH_API int aeth_downsample(aeth_ctx *ctx, const void *src_dev, size_t n_src,
 AETH_API int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src,
                                   void *dst, size_t n_dst, size_t elem_size);
 
+/* ---- modulation (SURVEY 8f "next" #1): src/modulation.rs --------------------------- */
+/* Modulation::modulate (:115-121): one symbol per `bits_per_symbol` input bytes (each byte is
+ * one bit, taken modulo 2 as the trait's default index() does, :107); index =
+ * bits[0] for BPSK (:9-12), (bits[1] << 1) + bits[0] for QPSK (:21-24); out[s] = table[index].
+ * table_host: 2 or 4 symbols, NULL = GENERIC_BPSK_TABLE / GENERIC_QPSK_TABLE (:77-92).
+ * nbits must be a multiple of bits_per_symbol (AETH_E_LEN) and n_out == nbits / bits_per_symbol. */
+AETH_API int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits_dev, size_t nbits, int bits_per_symbol,
+                           const aeth_cf32 *table_host, aeth_cf32 *out_dev, size_t n_out);
+/* Modulation::demod_naive: nearest table symbol by squared distance, the FIRST minimum wins
+ * (min_by keeps the first of equals).  compat != 0 reproduces the QPSK specialisation's
+ * output exactly (:33-56): it pushes `idx & 1` and `idx & 1u8 << 1` == idx & 2, i.e. the
+ * second bit comes out as 0 or 2; compat == 0 emits (idx >> 1) & 1.  BPSK follows the
+ * trait default (:133-144).  bits_out_dev receives nsym * bits_per_symbol bytes. */
+AETH_API int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym_dev, size_t nsym, int bits_per_symbol,
+                              const aeth_cf32 *table_host, uint8_t *bits_out_dev, size_t nbits_out, int compat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -492,6 +492,43 @@ void orc_qpsk_demod_naive(const orc_cf32 *sym, size_t nsym, uint8_t *bits_out)
     }
 }
 
+/* GENERIC_BPSK_TABLE :77 */
+static const orc_cf32 BPSK[2] = { {1.0f, 1.0f}, {-1.0f, -1.0f} };
+
+int orc_modulate(const uint8_t *bits, size_t nbits, int bps, const orc_cf32 *table, orc_cf32 *out)
+{
+    if (bps != 1 && bps != 2) return -1;
+    if (nbits % (size_t)bps) return -1;            /* chunks() would hand index() a short chunk */
+    const orc_cf32 *t = table ? table : (bps == 1 ? BPSK : QPSK);
+    for (size_t s = 0; s < nbits / (size_t)bps; s++) {
+        unsigned idx = (bps == 1) ? (bits[s] & 1u)                                   /* :9-12  */
+                                  : (((bits[2 * s + 1] & 1u) << 1) + (bits[2 * s] & 1u));   /* :21-24 */
+        out[s] = t[idx];                                                             /* :115-121 */
+    }
+    return 0;
+}
+
+int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *table, int compat, uint8_t *bits_out)
+{
+    if (bps != 1 && bps != 2) return -1;
+    const orc_cf32 *t = table ? table : (bps == 1 ? BPSK : QPSK);
+    const int ncand = bps == 1 ? 2 : 4;            /* trait default scans BITS_PER_SYMBOL*2 (:135) = 2 for BPSK */
+    for (size_t s = 0; s < nsym; s++) {
+        int best = 0; float bd = 0;
+        for (int i = 0; i < ncand; i++) {
+            float dr = sym[s].re - t[i].re, di = sym[s].im - t[i].im;
+            float d = dr * dr + di * di;
+            if (i == 0 || d < bd) { best = i; bd = d; }
+        }
+        if (bps == 1) bits_out[s] = (uint8_t)(best & 1);                             /* :143 */
+        else {
+            bits_out[2 * s] = (uint8_t)(best & 1);                                   /* :53 */
+            bits_out[2 * s + 1] = (uint8_t)(compat ? (best & 2) : ((best >> 1) & 1)); /* :54 */
+        }
+    }
+    return 0;
+}
+
 /* ======================================================================= */
 /* synthetic input                                                          */
 /* ======================================================================= */

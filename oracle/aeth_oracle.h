@@ -123,6 +123,10 @@ double orc_evm_aggregate_db_f64ref(const orc_cf32 *act, const orc_cf64 *ref, siz
 /* ---- modulation: src/modulation.rs ------------------ */
 void orc_qpsk_modulate(const uint8_t *bits, size_t nbits, orc_cf32 *out);        /* :21-24,:87-92,:115-121 */
 void orc_qpsk_demod_naive(const orc_cf32 *sym, size_t nsym, uint8_t *bits_out);  /* :33-56 (incl. `idx & 1u8 << 1` quirk) */
+/* generic forms: bps = 1 (BPSK, :5-15, demod by the trait default :133-144) or 2 (QPSK);
+ * table = NULL -> the generic tables (:77-92); compat = 0 emits (idx >> 1) & 1 for QPSK */
+int orc_modulate(const uint8_t *bits, size_t nbits, int bps, const orc_cf32 *table, orc_cf32 *out);
+int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *table, int compat, uint8_t *bits_out);
 
 /* ---- deterministic synthetic input (the build's own generator) ---------- */
 /* complex normal, unit power (sigma = 1/sqrt(2) per component), splitmix64 +

@@ -72,6 +72,8 @@ def lib():
             "orc_evm_aggregate_db_f64ref": (f64, [vp, vp, sz]),
             "orc_qpsk_modulate": (None, [vp, sz, vp]),
             "orc_qpsk_demod_naive": (None, [vp, sz, vp]),
+            "orc_modulate": (i32, [vp, sz, i32, vp, vp]),
+            "orc_demod_naive": (i32, [vp, sz, i32, vp, i32, vp]),
             "orc_synth_cnormal": (None, [C.c_uint64, vp, sz]),
             "orc_synth_lowpass_taps": (None, [sz, f64, vp]),
         }
@@ -272,6 +274,20 @@ def qpsk_modulate(bits):
 def qpsk_demod_naive(sym):
     sym = _c64(sym); out = np.empty(sym.size * 2, np.uint8)
     lib().orc_qpsk_demod_naive(_p(sym), sym.size, _p(out)); return out
+
+
+def modulate(bits, bps, table=None):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8); out = np.empty(bits.size // bps, np.complex64)
+    tp = _p(_c64(table)) if table is not None else None
+    if lib().orc_modulate(_p(bits), bits.size, bps, tp, _p(out)) != 0:
+        raise LengthMismatch("bit count is not a multiple of BITS_PER_SYMBOL")
+    return out
+
+
+def demod_naive(sym, bps, table=None, compat=True):
+    sym = _c64(sym); out = np.empty(sym.size * bps, np.uint8)
+    tp = _p(_c64(table)) if table is not None else None
+    lib().orc_demod_naive(_p(sym), sym.size, bps, tp, 1 if compat else 0, _p(out)); return out
 
 
 # ---- synthetic input ------------------------------------------------------------
