@@ -17,7 +17,8 @@ from .fft import Scale, HipFft, SIGN_REF_FWD, SIGN_REF_BWD  # noqa: E402
 from .fir import Fir                                      # noqa: E402
 from . import sampling                                    # noqa: E402
 from . import modulation                                  # noqa: E402
+from . import noise                                       # noqa: E402
 from .evm import assert_evm, evm_db                       # noqa: E402
 
 __all__ = ["AetherError", "LengthMismatch", "Context", "DeviceVec", "HostVec", "Scale", "HipFft",
-           "SIGN_REF_FWD", "SIGN_REF_BWD", "Fir", "sampling", "modulation", "assert_evm", "evm_db"]
+           "SIGN_REF_FWD", "SIGN_REF_BWD", "Fir", "sampling", "modulation", "noise", "assert_evm", "evm_db"]

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "aeth_host_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
     "aeth_modulate": (i32, [vp, vp, sz, i32, vp, vp, sz]),
     "aeth_demod_naive": (i32, [vp, vp, sz, i32, vp, vp, sz, i32]),
+    "aeth_awgn_apply": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
 }
 
 _lib = None

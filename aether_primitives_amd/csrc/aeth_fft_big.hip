@@ -136,7 +136,7 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch)
     const size_t grid = batch * (plan->n2 / G);
     hipLaunchKernelGGL((fourstep_cols<C, S>), dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
                        (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
-                       getenv("AETH_4S_NOTW") ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
+                       aeth::tuning_int("AETH_4S_NOTW", 0) ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

@@ -174,15 +174,10 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a)
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
     FmiArgs b = a;
-    { const char *d = getenv("AETH_FIR_DBG"); b.dbg = d ? atoi(d) : 0; if (b.dbg & 4) b.twL = nullptr; }
-    if constexpr (C::N == 2048) {
-        const char *g = getenv("AETH_FIR_GRID");
-        if (g) grid = atoi(g) < grid ? atoi(g) : grid;
-    }
-    if constexpr (C::N == 2048) {
-        const char *v = getenv("AETH_FIR_VARIANT");
-        if (v && atoi(v) == 3) { hipLaunchKernelGGL((fmi_kernel<C, SCALED, 3>), dim3(grid), dim3(C::WG), 0, ctx->stream, b); AETH_HIP(hipGetLastError()); return AETH_OK; }
-    }
+    b.dbg = aeth::tuning_int("AETH_FIR_DBG", 0);            // 1: no prefetch loads, 2: no stores, 4: gather twiddles
+    if (b.dbg & 4) b.twL = nullptr;
+    const int g = aeth::tuning_int("AETH_FIR_GRID", 0);
+    if (g > 0 && g < grid) grid = g;
     hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1>), dim3(grid), dim3(C::WG), 0, ctx->stream, b);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
@@ -191,10 +186,6 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a)
 int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a)
 {
     const bool scaled = !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
-    {
-        const char *v = getenv("AETH_FIR_VARIANT");
-        if (fft_len == 2048 && v && atoi(v) == 8 && !scaled) { FmiArgs c = a; c.twL = nullptr; return launch_fmi<Cfg<2048, 8, 8, 8, 8, 4>, false>(ctx, c); }
-    }
 #define AETH_BODY(NN)                                                            \
     return scaled ? launch_fmi<typename CfgFor<NN>::type, true>(ctx, a)          \
                   : launch_fmi<typename CfgFor<NN>::type, false>(ctx, a)

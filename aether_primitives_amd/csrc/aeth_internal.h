@@ -30,6 +30,10 @@ int hip_fail(hipError_t e, const char *what);
 // ensure staging slot `i` holds >= bytes (device + pinned host)
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes);
 
+// Tuning knobs (tools/tune_*.py): environment integers that are consulted ONLY when the
+// process was started with AETH_TUNING=1; a normal run never reads them.
+int tuning_int(const char *name, int dflt);
+
 inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1,0 +1,79 @@
+// aeth_noise.hip -- additive white Gaussian noise on a device-resident signal
+// (reference: src/noise.rs:29-59, Awgn::new / next / apply).  SURVEY 8f "next" row #1.
+//
+// The arithmetic around the random stream follows the reference exactly:
+//   scale = power.sqrt()                          (noise.rs:35)
+//   next  = (N(0,1) as f32 * scale, N(0,1) as f32 * scale)      (noise.rs:39-43)
+//   apply : s += next.scale(scale)                (noise.rs:53-59: scaled TWICE, so the noise
+//                                                  amplitude is proportional to `power`)
+// The stream itself is the build's own counter-based generator (aeth_rng.h): the reference's
+// StdRng/ziggurat sequence cannot be reproduced.  Compiled with -ffp-contract=off.
+// HBM-bound at 16 B/sample; one lane per PAIR of samples (one Philox call, one 16-byte access).
+#include "aeth_internal.h"
+
+#define AETH_RNG_FN __host__ __device__ static inline
+#include "aeth_rng.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__ x, size_t n, float scale,
+                                                            uint64_t seed, uint64_t offset, int wide)
+{
+    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;       // pair index
+    const size_t i0 = 2 * p;
+    if (i0 >= n) return;
+    // stream position of sample i is offset + i; an odd offset shifts the pairing, so draw per sample then
+    float n0r, n0i, n1r = 0.f, n1i = 0.f;
+    if ((offset & 1) == 0) {
+        uint32_t w[4];
+        const uint64_t call = (offset + i0) >> 1;
+        aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
+        aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
+    } else {
+        aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
+        if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
+    }
+    if (wide && i0 + 1 < n) {
+        float4 v = *reinterpret_cast<float4 *>(x + i0);
+        v.x = v.x + (n0r * scale) * scale;          // noise.rs:41 then :58
+        v.y = v.y + (n0i * scale) * scale;
+        v.z = v.z + (n1r * scale) * scale;
+        v.w = v.w + (n1i * scale) * scale;
+        *reinterpret_cast<float4 *>(x + i0) = v;
+    } else {
+        float2 a = x[i0];
+        a.x = a.x + (n0r * scale) * scale;
+        a.y = a.y + (n0i * scale) * scale;
+        x[i0] = a;
+        if (i0 + 1 < n) {
+            float2 b = x[i0 + 1];
+            b.x = b.x + (n1r * scale) * scale;
+            b.y = b.y + (n1i * scale) * scale;
+            x[i0 + 1] = b;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal, size_t n, float power, uint64_t seed, uint64_t offset)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    if (n == 0) return AETH_OK;
+    AETH_REQUIRE(signal, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(signal), AETH_E_ALIGN, "signal not 8-byte aligned");
+    AETH_REQUIRE(power >= 0.0f, AETH_E_ARG, "noise power must be >= 0");
+    const float scale = sqrtf(power);                       // noise.rs:35
+    const size_t pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(awgn_apply_kernel, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<float2 *>(signal), n, scale, seed, offset, aeth::aligned16(signal) ? 1 : 0);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+}  // extern "C"

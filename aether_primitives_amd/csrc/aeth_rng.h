@@ -1,0 +1,94 @@
+// aeth_rng.h -- counter-based complex normal generator used by the AWGN kernel.
+// Plain C, integer + f32 (+,-,*,/,sqrt) only, fixed operation order: compiled with
+// -ffp-contract=off it is bit-reproducible between host compilers and the GPU.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#ifndef AETH_RNG_FN
+#define AETH_RNG_FN static inline
+#endif
+
+/* ---- counter-based complex normal generator (the BUILD's own; the reference's
+ * StdRng + rand_distr::Normal stream, src/noise.rs:2-4,29-44, cannot be reproduced).
+ * Philox4x32-10 keyed by the seed, counter = pair index; one call -> four 32-bit words ->
+ * two complex samples by Box-Muller.  Every floating-point step is +,-,*,sqrt on f32 in a
+ * fixed order (no libm), so CPU oracle and GPU kernel agree bit for bit when both are
+ * compiled without contraction. ---- */
+AETH_RNG_FN void aeth_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                    uint32_t out[4])
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* natural log of u in (0, 1], |error| ~ 1e-7 relative: u = m * 2^e, m in [sqrt(.5), sqrt(2)),
+ * ln m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^9 */
+AETH_RNG_FN float aeth_rng_log(float u)
+{
+    union { float f; uint32_t i; } v; v.f = u;
+    int e = (int)((v.i >> 23) & 0xff) - 127;
+    v.i = (v.i & 0x007fffffu) | 0x3f800000u;               /* m in [1, 2) */
+    float m = v.f;
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float s2 = s * s;
+    float p = 0.11111111f;                                  /* 1/9 */
+    p = p * s2 + 0.14285715f;                               /* 1/7 */
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.33333334f;
+    p = p * s2 + 1.0f;
+    return (float)e * 0.69314718f + 2.0f * s * p;
+}
+
+/* (cos, sin)(2 pi w / 2^24), w a 24-bit integer: quadrant by the top two bits, then
+ * Taylor polynomials of sin/cos(pi/2 * t), t in [0, 1) */
+AETH_RNG_FN void aeth_rng_cossin(uint32_t w24, float *c, float *s)
+{
+    const uint32_t q = (w24 >> 22) & 3u;
+    const float t = (float)(w24 & 0x3fffffu) * (1.0f / 4194304.0f);
+    const float x = t * 1.57079633f, x2 = x * x;
+    float sp = -2.50521084e-08f;                            /* -1/11! */
+    sp = sp * x2 + 2.75573192e-06f;
+    sp = sp * x2 - 1.98412698e-04f;
+    sp = sp * x2 + 8.33333333e-03f;
+    sp = sp * x2 - 1.66666667e-01f;
+    sp = sp * x2 + 1.0f;
+    sp = sp * x;
+    float cp = -2.75573192e-07f;                            /* -1/10! */
+    cp = cp * x2 + 2.48015873e-05f;
+    cp = cp * x2 - 1.38888889e-03f;
+    cp = cp * x2 + 4.16666667e-02f;
+    cp = cp * x2 - 0.5f;
+    cp = cp * x2 + 1.0f;
+    if (q == 0) { *c = cp; *s = sp; }
+    else if (q == 1) { *c = -sp; *s = cp; }
+    else if (q == 2) { *c = -cp; *s = -sp; }
+    else { *c = sp; *s = -cp; }
+}
+
+/* two 32-bit words -> one complex standard normal (unit variance per component) */
+AETH_RNG_FN void aeth_rng_normal_pair(uint32_t a, uint32_t b, float *z0, float *z1)
+{
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);     /* (0, 1] */
+    const float r = sqrtf(-2.0f * aeth_rng_log(u1));
+    float c, s;
+    aeth_rng_cossin(b >> 8, &c, &s);
+    *z0 = r * c;
+    *z1 = r * s;
+}
+
+/* complex sample number `idx` of stream (seed): samples 2k and 2k+1 share Philox call k */
+AETH_RNG_FN void aeth_rng_cnormal(uint64_t seed, uint64_t idx, float *re, float *im)
+{
+    uint32_t w[4];
+    const uint64_t call = idx >> 1;
+    aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    if (idx & 1) aeth_rng_normal_pair(w[2], w[3], re, im);
+    else aeth_rng_normal_pair(w[0], w[1], re, im);
+}

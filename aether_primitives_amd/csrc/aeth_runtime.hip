@@ -3,6 +3,7 @@
 // keeps implicit in Rust ownership (Vec<cf32>, Cfft.tmp: src/fft.rs:134-159).
 #include "aeth_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -25,6 +26,14 @@ int hip_fail(hipError_t e, const char *what)
 {
     return set_error(e == hipErrorOutOfMemory ? AETH_E_NOMEM : AETH_E_HIP, "HIP error %d (%s) in %s",
                      (int)e, hipGetErrorString(e), what);
+}
+
+int tuning_int(const char *name, int dflt)
+{
+    static const bool enabled = [] { const char *e = getenv("AETH_TUNING"); return e && atoi(e) != 0; }();
+    if (!enabled) return dflt;
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes)

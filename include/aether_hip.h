@@ -221,6 +221,18 @@ AETH_API int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits_dev, size_t nbits,
 AETH_API int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym_dev, size_t nsym, int bits_per_symbol,
                               const aeth_cf32 *table_host, uint8_t *bits_out_dev, size_t nbits_out, int compat);
 
+/* ---- noise (SURVEY 8f "next" #1): src/noise.rs ------------------------------------- */
+/* Awgn::apply (:53-59) on a device-resident signal: s[i] += next().scale(scale) with
+ * scale = sqrt(power) (:35) and next() = (z.re * scale, z.im * scale) (:39-43) -- the
+ * reference scales twice, so the noise amplitude is proportional to `power`; reproduced.
+ * z comes from the library's own counter-based generator (Philox4x32-10 + Box-Muller,
+ * position `offset + i` of stream `seed`; DEFAULT seed of the reference is 815, :6): the
+ * reference's StdRng stream is not reproducible, results agree bit for bit with the CPU
+ * restatement of THIS generator only.  Consecutive calls continue a stream by passing
+ * offset += n, as the reference's generator object would. */
+AETH_API int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal_dev, size_t n, float power, uint64_t seed,
+                             uint64_t offset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -530,6 +530,24 @@ int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *t
 }
 
 /* ======================================================================= */
+/* noise: src/noise.rs                                                      */
+/* ======================================================================= */
+#include "awgn_restatement.inc"
+
+void orc_rng_cnormal(uint64_t seed, uint64_t idx, float *re, float *im) { aeth_rng_cnormal(seed, idx, re, im); }
+
+void orc_awgn_apply(orc_cf32 *signal, size_t n, float power, uint64_t seed, uint64_t offset)
+{
+    const float scale = sqrtf(power);                           /* noise.rs:35 */
+    for (size_t i = 0; i < n; i++) {
+        float zr, zi;
+        aeth_rng_cnormal(seed, offset + i, &zr, &zi);
+        signal[i].re = signal[i].re + (zr * scale) * scale;     /* noise.rs:41 then :58 */
+        signal[i].im = signal[i].im + (zi * scale) * scale;     /* noise.rs:42 then :58 */
+    }
+}
+
+/* ======================================================================= */
 /* synthetic input                                                          */
 /* ======================================================================= */
 

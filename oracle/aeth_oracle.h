@@ -128,6 +128,12 @@ void orc_qpsk_demod_naive(const orc_cf32 *sym, size_t nsym, uint8_t *bits_out); 
 int orc_modulate(const uint8_t *bits, size_t nbits, int bps, const orc_cf32 *table, orc_cf32 *out);
 int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *table, int compat, uint8_t *bits_out);
 
+/* ---- noise: src/noise.rs:29-59 around the build's counter-based generator ---- */
+/* z = complex standard normal number `idx` of stream `seed` (awgn_restatement.inc) */
+void orc_rng_cnormal(uint64_t seed, uint64_t idx, float *re, float *im);
+/* Awgn::apply: s[i] += (z * scale) * scale, scale = sqrtf(power) (noise.rs:35,41-42,58) */
+void orc_awgn_apply(orc_cf32 *signal, size_t n, float power, uint64_t seed, uint64_t offset);
+
 /* ---- deterministic synthetic input (the build's own generator) ---------- */
 /* complex normal, unit power (sigma = 1/sqrt(2) per component), splitmix64 +
  * Box-Muller in f64, rounded to f32.  Seed 815 = noise.rs:6. */

@@ -21,7 +21,7 @@ SIGN_REF_FWD, SIGN_REF_BWD = +1, -1
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("aeth_oracle.c", "aeth_oracle.h", "fft_template.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("aeth_oracle.c", "aeth_oracle.h", "fft_template.inc", "awgn_restatement.inc")]
     have_src = all(os.path.exists(s) for s in srcs)
     stale = (not os.path.exists(_SO)) or (
         have_src and os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs))
@@ -74,6 +74,7 @@ def lib():
             "orc_qpsk_demod_naive": (None, [vp, sz, vp]),
             "orc_modulate": (i32, [vp, sz, i32, vp, vp]),
             "orc_demod_naive": (i32, [vp, sz, i32, vp, i32, vp]),
+            "orc_awgn_apply": (None, [vp, sz, f32, C.c_uint64, C.c_uint64]),
             "orc_synth_cnormal": (None, [C.c_uint64, vp, sz]),
             "orc_synth_lowpass_taps": (None, [sz, f64, vp]),
         }
@@ -288,6 +289,10 @@ def demod_naive(sym, bps, table=None, compat=True):
     sym = _c64(sym); out = np.empty(sym.size * bps, np.uint8)
     tp = _p(_c64(table)) if table is not None else None
     lib().orc_demod_naive(_p(sym), sym.size, bps, tp, 1 if compat else 0, _p(out)); return out
+
+
+def awgn_apply(signal, power, seed=815, offset=0):
+    s = _c64(signal).copy(); lib().orc_awgn_apply(_p(s), s.size, float(np.float32(power)), int(seed), int(offset)); return s
 
 
 # ---- synthetic input ------------------------------------------------------------

@@ -60,6 +60,11 @@ extern "C" {
 
     pub fn aeth_host_interpolate(ctx: *mut aeth_ctx, src: *const cf32, n_src: usize, dst: *mut cf32, cap: usize,
                                  n_between: usize, compat_im: c_int, n_written: *mut usize) -> c_int;
+    pub fn aeth_modulate(ctx: *mut aeth_ctx, bits: *const u8, nbits: usize, bits_per_symbol: c_int,
+                         table: *const cf32, out: *mut cf32, n_out: usize) -> c_int;
+    pub fn aeth_demod_naive(ctx: *mut aeth_ctx, sym: *const cf32, nsym: usize, bits_per_symbol: c_int,
+                            table: *const cf32, bits_out: *mut u8, nbits_out: usize, compat: c_int) -> c_int;
+    pub fn aeth_awgn_apply(ctx: *mut aeth_ctx, signal: *mut cf32, n: usize, power: c_float, seed: u64, offset: u64) -> c_int;
     pub fn aeth_host_downsample(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void,
                                 n_dst: usize, elem_size: usize) -> c_int;
 }

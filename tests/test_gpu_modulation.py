@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import aether_primitives_amd as ap
-from aether_primitives_amd import HipFft, Scale, modulation
+from aether_primitives_amd import HipFft, Scale, modulation, noise
 from helpers import expand, load_kat, bits_equal, rand_c64
 
 pytestmark = pytest.mark.gpu
@@ -47,6 +47,39 @@ def test_demod_quirk_and_ties(ctx, oracle):
         q.modulate(np.array([0, 1, 1], np.uint8))               # not a multiple of BITS_PER_SYMBOL
 
 
+@pytest.mark.parametrize("n,offset", [(1, 0), (2, 0), (7, 0), (7, 3), (4096, 0), (100001, 5), (1 << 20, 1 << 33)])
+def test_awgn_apply_bit_exact(ctx, oracle, n, offset):
+    """Awgn::apply (noise.rs:53-59) around the build's counter-based generator: bit for bit
+    against its CPU restatement, incl. odd stream offsets, odd lengths, misaligned slices."""
+    x = rand_c64(n, n + 1)
+    for power in (1.0, 0.01):
+        d = ctx.vec(x)
+        g = noise.new(ctx, power, 815); g.offset = offset
+        g.apply(d.slice(0, n))
+        assert bits_equal(d.to_host()[:n], oracle.awgn_apply(x[:n], power, 815, offset))
+        assert bits_equal(d.to_host()[n:], x[n:])                       # nothing past the slice moved
+        d = ctx.vec(x); g = noise.new(ctx, power, 815); g.offset = offset
+        g.apply(d.slice(1, n + 1))                                      # 8- but not 16-byte aligned view
+        assert bits_equal(d.to_host()[1:], oracle.awgn_apply(x[1:], power, 815, offset))
+
+
+def test_awgn_stream_continues_and_statistics(ctx, oracle):
+    n = 1 << 21
+    z = ctx.vec(np.zeros(n, np.complex64))
+    g = noise.generator(ctx)                                            # power 1, seed 815 (noise.rs:8-11)
+    g.apply(z.slice(0, 1000)); g.apply(z.slice(1000, 1001)); g.apply(z.slice(1001, n))   # three calls = one stream
+    h = z.to_host()
+    assert bits_equal(h, oracle.awgn_apply(np.zeros(n, np.complex64), 1.0, 815, 0))
+    assert abs(h.real.mean()) < 3e-3 and abs(h.imag.mean()) < 3e-3
+    assert abs(h.real.var() - 1) < 5e-3 and abs(h.imag.var() - 1) < 5e-3
+    assert abs(np.corrcoef(h.real, h.imag)[0, 1]) < 3e-3
+    # the reference scales twice (noise.rs:41-42, 58): amplitude ~ power, variance ~ power^2
+    z2 = ctx.vec(np.zeros(n, np.complex64)); noise.new(ctx, 0.01, 1).apply(z2)
+    assert abs(z2.to_host().real.var() / 1e-4 - 1) < 1e-2
+    other = ctx.vec(np.zeros(16, np.complex64)); noise.new(ctx, 1.0, 816).apply(other)
+    assert not bits_equal(other.to_host(), h[:16])                      # different seed, different stream
+
+
 def test_c4_chain(ctx, oracle):
     """QPSK mod -> AWGN (power 0.01, examples/modem.rs:25) -> per 2048-frame rfft * conj-reference
     -> rifft -> hard demod.  Correlating against a unit impulse reference leaves the frame
@@ -56,8 +89,7 @@ def test_c4_chain(ctx, oracle):
     bits = rng.integers(0, 2, 2 * n * frames, dtype=np.uint8)
     q = modulation.qpsk(ctx)
     tx = q.modulate(bits)
-    noise = (rng.standard_normal(2 * n * frames).astype(np.float32) * np.float32(0.01)).view(np.complex64)
-    tx.vec_add(ctx.vec(noise))
+    noise.new(ctx, 0.01, 815).apply(tx)                                 # examples/modem.rs:25
     ref = np.zeros(n, np.complex64); ref[0] = 1
     f = HipFft(ctx, n)
     sig = ctx.vec(ref); f.ifwd(sig, Scale.NONE); sig.vec_conj()            # conj of the reference spectrum

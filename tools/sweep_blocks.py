@@ -3,6 +3,7 @@
 separates the per-launch fixed cost (prologue + pipeline fill + drain) from the
 steady-state rate."""
 import os, sys, statistics
+os.environ.setdefault('AETH_TUNING', '1')   # enables the library's AETH_* tuning knobs
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aether_primitives_amd as ap
 from bench import synth_stream, lowpass_taps

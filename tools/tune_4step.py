@@ -1,4 +1,5 @@
 import os, sys, statistics
+os.environ.setdefault('AETH_TUNING', '1')   # enables the library's AETH_* tuning knobs
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import aether_primitives_amd as ap

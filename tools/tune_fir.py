@@ -3,6 +3,7 @@
 the AETH_FIR_* knobs, interleaved rounds in ONE process (cdna guide rule 24).
 usage: tune_fir.py [steps] [stream_len] -- "K=V K=V" "K=V" ...   (each quoted string = one variant)"""
 import os, sys, statistics
+os.environ.setdefault('AETH_TUNING', '1')   # enables the library's AETH_* tuning knobs
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aether_primitives_amd as ap
