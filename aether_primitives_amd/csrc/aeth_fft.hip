@@ -88,7 +88,7 @@ int dispatch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t ba
 template <class C>
 int build_lane_table(aeth_fft *plan)
 {
-    const size_t elems = (size_t)C::TW * C::T;
+    const size_t elems = (size_t)LaneTable<C>::ELEMS;
     AETH_HIP(hipMalloc((void **)&plan->tw_lane_dev, elems * sizeof(float2)));
     hipLaunchKernelGGL((build_lane_twiddles<C>), dim3(1), dim3(C::T < 64 ? 64 : C::T), 0, plan->ctx->stream,
                        (const cf *)plan->tw_dev, (cf *)plan->tw_lane_dev);

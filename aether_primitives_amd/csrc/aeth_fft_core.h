@@ -333,16 +333,51 @@ __device__ __forceinline__ void load_twiddles(cf (&tw)[C::TW], const cf *__restr
     if constexpr (C::NPASS > 3) load_tw_pass<C, 3>(tw, twN, tid);
 }
 
-// The same registers from the plan's per-lane table twL[slot * T + tid] (built once per
-// plan by build_lane_twiddles): one coalesced 8-byte load per slot instead of a 64-way
-// gather from the master table, which matters because every launch pays this prologue.
+// The same registers from the plan's per-lane table (built once per plan by
+// build_lane_twiddles): one coalesced load per register instead of a 64-way gather from
+// the master table, which matters because every launch pays this prologue.
+// Layout: the registers of pass s, butterfly b, power r form row (s, b, r).  The
+// twiddle depends on the lane only through k = (tid + b*T) mod p_s, so a row holds
+// min(p_s, T) entries: T when p_s >= T (one per lane), p_s when the pass right after
+// the first exchange repeats every p_s lanes (2048 = 16*16*8: 16 entries instead of 128;
+// the table every workgroup pulls through L2 shrinks from 58 KiB to 30 KiB).
+template <class C> struct LaneTable {
+    static constexpr int rowlen(int pass) { return C::pbefore(pass) < C::T ? C::pbefore(pass) : C::T; }
+    static constexpr int rows(int pass) { return C::twcount(pass); }
+    static constexpr int offset(int pass)
+    {
+        int o = 0;
+        for (int i = 1; i < pass; i++) o += rows(i) * rowlen(i);
+        return o;
+    }
+    static constexpr int ELEMS = offset(C::NPASS) > 0 ? offset(C::NPASS) : 1;
+};
+
+template <class C, int PASS>
+__device__ __forceinline__ void lane_tw_pass(cf (&tw)[C::TW], const cf *__restrict__ twL, int tid, bool store)
+{
+    constexpr int R = C::radix(PASS), B = C::P / R, p = C::pbefore(PASS);
+    constexpr int L = LaneTable<C>::rowlen(PASS);
+    cf *wr = const_cast<cf *>(twL);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const int lane = (p < C::T) ? ((tid + b * C::T) & (p - 1)) : tid;
+#pragma unroll
+        for (int r = 1; r < R; r++) {
+            const int slot = C::twoff(PASS) + b * (R - 1) + (r - 1);
+            const int idx = LaneTable<C>::offset(PASS) + (b * (R - 1) + (r - 1)) * L + lane;
+            if (store) wr[idx] = tw[slot];
+            else tw[slot] = twL[idx];
+        }
+    }
+}
+
 template <class C>
 __device__ __forceinline__ void load_twiddles_lane(cf (&tw)[C::TW], const cf *__restrict__ twL, int tid)
 {
-    if constexpr (C::NPASS > 1) {
-#pragma unroll
-        for (int s = 0; s < C::TW; s++) tw[s] = twL[s * C::T + tid];
-    }
+    if constexpr (C::NPASS > 1) lane_tw_pass<C, 1>(tw, twL, tid, false);
+    if constexpr (C::NPASS > 2) lane_tw_pass<C, 2>(tw, twL, tid, false);
+    if constexpr (C::NPASS > 3) lane_tw_pass<C, 3>(tw, twL, tid, false);
 }
 
 template <class C>
@@ -351,11 +386,10 @@ __global__ void build_lane_twiddles(const cf *__restrict__ twN, cf *__restrict__
     const int tid = threadIdx.x;
     if (tid >= C::T) return;
     cf tw[C::TW];
-    load_twiddles<C>(tw, twN, tid);
-    if constexpr (C::NPASS > 1) {
-#pragma unroll
-        for (int s = 0; s < C::TW; s++) twL[s * C::T + tid] = tw[s];
-    }
+    load_twiddles<C>(tw, twN, tid);          // (lanes that share a row entry write the same value)
+    if constexpr (C::NPASS > 1) lane_tw_pass<C, 1>(tw, twL, tid, true);
+    if constexpr (C::NPASS > 2) lane_tw_pass<C, 2>(tw, twL, tid, true);
+    if constexpr (C::NPASS > 3) lane_tw_pass<C, 3>(tw, twL, tid, true);
 }
 
 // Exchange buffers: where two LDS images of the frame fit (C::DB) consecutive exchanges

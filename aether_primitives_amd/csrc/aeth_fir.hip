@@ -48,7 +48,7 @@ struct FmiArgs {
     long long nblocks;
     int hop, ov, nhist;
     float s_fwd, s_bwd;
-    int dbg;              // tuning only (AETH_FIR_DBG): 1 = skip prefetch loads, 2 = skip stores
+    int dbg;              // tuning only (AETH_FIR_DBG): 4 = gather the twiddles instead of the per-lane table
 };
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -75,10 +75,8 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
 #pragma unroll
             for (int m = 0; m < C::P; m++)
                 x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 0));
-            // window samples older than the ntaps-1 the outputs depend on are forced to zero, so a
-            // block is a function of exactly x[out0-(ntaps-1) .. out0+hop): shards of one stream
-            // (history = ntaps-1 samples) then reproduce the unsharded run bit for bit
-            if (tid < a.ov - a.nhist) x[0] = mk(0.f, 0.f);
+            // (the window's oldest ov-nhist samples are zeroed when the window is consumed: doing it
+            // here would put a wait for the load right behind its issue)
             return;
         }
     }
@@ -94,6 +92,23 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
     }
 }
 
+// Branch-free form for the steady state of one-frame workgroups (win0 >= 0 guaranteed by
+// the caller): a block past the end gets a zero-length descriptor, so the loads still
+// issue -- and return zeros without touching memory.  No divergent path means hipcc can
+// COUNT the loads in flight (vmcnt(N)) instead of falling back to vmcnt(0).
+template <class C>
+__device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
+{
+    const bool active = blk < a.nblocks;
+    const long long win0 = active ? blk * a.hop - a.ov : 0;
+    long long left = a.n - win0;
+    const int bytes = active ? (int)(left < C::N ? left : C::N) * 8 : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < C::P; m++)
+        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 0));
+}
+
 template <class C, bool SCALED>
 __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
 {
@@ -104,13 +119,14 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
         int bytes = (int)(left < C::N ? left : C::N) * 8;   // stores past the end are dropped by the range check
         auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + base, 0, bytes, 0x00020000);
         const cf ss = mk(a.s_bwd, a.s_bwd);
+        // no branch around the stores either: window elements in front of the valid part
+        // (e < ov) get an offset past the descriptor's range and are dropped by its check
 #pragma unroll
         for (int m = 0; m < C::P; m++) {
             const int e = tid + m * C::T;
-            if (e >= a.ov) {
-                cf v = SCALED ? cscale_k(w[m], ss) : w[m];
-                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, e * 8, 0, 0);
-            }
+            const int off = (e >= a.ov) ? e * 8 : 0x7ffffff0;
+            cf v = SCALED ? cscale_k(w[m], ss) : w[m];
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, 0);
         }
     } else {
 #pragma unroll
@@ -144,14 +160,28 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
     cf H[C::P];
 #pragma unroll
     for (int m = 0; m < C::P; m++) H[m] = a.Hf[tid + m * C::T];
+    // Drain the table loads HERE, once.  Otherwise hipcc places their counted waits at the first
+    // uses inside the loop body, where they run every iteration and end in vmcnt(0) halfway
+    // through each block -- forcing the prefetched window AND the previous block's stores to
+    // complete there instead of riding under the whole block.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only
 #pragma unroll 1
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const long long blk = g * C::F + fl;
         cf w[C::P];
 #pragma unroll
         for (int m = 0; m < C::P; m++) w[m] = nx[m];
+        // window samples older than the ntaps-1 the outputs depend on are forced to zero, so a
+        // block is a function of exactly x[out0-(ntaps-1) .. out0+hop): shards of one stream
+        // (history = ntaps-1 samples) then reproduce the unsharded run bit for bit
+        if constexpr (C::F == 1) { if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f); }
         const long long gn = g + gridDim.x;
-        if (gn < ngroups && !(a.dbg & 1)) load_window<C>(nx, a, gn * C::F + fl, tid);
+        if constexpr (C::F == 1) {
+            // gn >= gridDim.x >= 1, so the window never starts before the stream: descriptor path
+            load_window_srd<C>(nx, a, gn, tid);
+        } else {
+            if (gn < ngroups) load_window<C>(nx, a, gn * C::F + fl, tid);
+        }
 
         fft_in_regs<C, +1, 0>(w, tw, lds, tid);             // vec_rfft: the reference's fwd (+j exponent)
         if constexpr (SCALED) {
@@ -162,7 +192,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
 #pragma unroll
         for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);             // vec_mul (vecops.rs:99-112)
         fft_in_regs<C, -1, fft_next_par<C>(0)>(w, tw, lds, tid);   // vec_rifft: bwd (-j); two transforms leave the parity even
-        if (!(a.dbg & 2)) store_block<C, SCALED>(w, a, blk, tid);
+        store_block<C, SCALED>(w, a, blk, tid);
     }
 }
 
@@ -174,7 +204,7 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a)
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
     FmiArgs b = a;
-    b.dbg = aeth::tuning_int("AETH_FIR_DBG", 0);            // 1: no prefetch loads, 2: no stores, 4: gather twiddles
+    b.dbg = aeth::tuning_int("AETH_FIR_DBG", 0);            // 4: gather twiddles from the master table
     if (b.dbg & 4) b.twL = nullptr;
     const int g = aeth::tuning_int("AETH_FIR_GRID", 0);
     if (g > 0 && g < grid) grid = g;
