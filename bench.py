@@ -110,7 +110,7 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:                 # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

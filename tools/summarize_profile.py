@@ -14,8 +14,8 @@ KERNEL = "fmi_kernel"
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)     # newest run
+    return f[-1] if f else None
 
 
 out = {"tag": tag, "command": "python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"}
