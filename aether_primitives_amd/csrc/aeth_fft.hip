@@ -62,6 +62,50 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
     }
 }
 
+// One-frame-per-workgroup sizes (N >= 1024): the same pipeline as the fused FIR kernel --
+// branch-free loop, frames through buffer descriptors (a zero-length descriptor turns the
+// prefetch of a frame past the batch into a no-op), next frame prefetched into registers
+// while this one is transformed, table loads drained once before the loop.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <class C, int S>
+__global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf *out, const cf *__restrict__ twL,
+                                                                 size_t batch, float scale)
+{
+    static_assert(C::F == 1, "one frame per workgroup");
+    __shared__ cf lds[C::LDS_TOTAL];
+    const int tid = threadIdx.x;
+    auto fetch = [&](cf (&x)[C::P], size_t frame) {
+        const bool active = frame < batch;
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(in + (active ? frame : 0) * C::N), 0,
+                                                    active ? C::N * 8 : 0, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < C::P; m++)
+            x[m] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 0));
+    };
+    cf nx[C::P];
+    fetch(nx, blockIdx.x);
+    cf tw[C::TW];
+    load_twiddles_lane<C>(tw, twL, tid);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) once, not inside the loop (see aeth_fir.hip)
+    const cf ss = mk(scale, scale);
+    bool par = false;
+#pragma unroll 1
+    for (size_t g = blockIdx.x; g < batch; g += gridDim.x) {
+        cf w[C::P];
+#pragma unroll
+        for (int m = 0; m < C::P; m++) w[m] = nx[m];
+        fetch(nx, g + gridDim.x);
+        if (fft_next_par<C>(0) == 0 || !par) fft_in_regs<C, S, 0>(w, tw, lds, tid);
+        else fft_in_regs<C, S, 1>(w, tw, lds, tid);
+        par = (fft_next_par<C>(0) != 0) && !par;
+        auto ws = __builtin_amdgcn_make_buffer_rsrc(out + g * C::N, 0, C::N * 8, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < C::P; m++)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, 0);
+    }
+}
+
 template <class C>
 int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
@@ -70,6 +114,18 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
     size_t cap = (size_t)ctx->num_cus * 8;
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
+    if constexpr (C::F == 1) {
+        // resident workgroups only: 4 per CU (the register prefetch puts these kernels at 2 waves per SIMD)
+        size_t cap2 = (size_t)ctx->num_cus * (512 / C::WG);
+        int grid2 = (int)(batch < cap2 ? batch : cap2);
+        if (grid2 < 1) grid2 = 1;
+        if (!aeth::tuning_int("AETH_FFT_NOSTREAM", 0)) {
+            if (sign > 0) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, +1>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
+            else          hipLaunchKernelGGL((fft_pow2_stream_kernel<C, -1>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
+            AETH_HIP(hipGetLastError());
+            return AETH_OK;
+        }
+    }
     if (sign > 0)
         hipLaunchKernelGGL((fft_pow2_kernel<C, +1>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
     else
@@ -353,6 +409,7 @@ int fft_ensure_tmp(aeth_fft *plan, size_t elems)
 int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
     if (batch == 0 || plan->len == 0) return AETH_OK;
+    aeth::DeviceGuard dev_guard(plan->ctx->device);
     switch (plan->algo) {
     case FFT_ALGO_POW2:  return dispatch_pow2(plan, in, out, batch, sign, scale);
     case FFT_ALGO_MIXED: return launch_mixed(plan, in, out, batch, sign, scale);

@@ -215,6 +215,7 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a)
 
 int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a)
 {
+    aeth::DeviceGuard dev_guard(ctx->device);
     const bool scaled = !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
 #define AETH_BODY(NN)                                                            \
     return scaled ? launch_fmi<typename CfgFor<NN>::type, true>(ctx, a)          \

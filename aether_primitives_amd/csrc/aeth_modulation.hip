@@ -79,6 +79,7 @@ int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, con
     AETH_REQUIRE(nbits % (size_t)bps == 0, AETH_E_LEN, "bit count %zu is not a multiple of BITS_PER_SYMBOL %d", nbits, bps);
     AETH_REQUIRE(n_out == nbits / (size_t)bps, AETH_E_LEN, "output holds %zu symbols, input gives %zu", n_out, nbits / (size_t)bps);
     if (n_out == 0) return AETH_OK;
+    aeth::DeviceGuard dev_guard(ctx->device);
     AETH_REQUIRE(bits && out, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(aeth::aligned8(out) && ((uintptr_t)bits % (size_t)bps) == 0, AETH_E_ALIGN, "pointer alignment");
     if (bps == 1) hipLaunchKernelGGL(modulate_kernel<1>, dim3(grid_for(n_out)), dim3(kBlock), 0, ctx->stream, bits, (float2 *)out, n_out, t);
@@ -95,6 +96,7 @@ int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym, size_t nsym, int bps, 
     int rc = fill_table(t, bps, table); if (rc) return rc;
     AETH_REQUIRE(nbits_out == nsym * (size_t)bps, AETH_E_LEN, "output holds %zu bits, input gives %zu", nbits_out, nsym * (size_t)bps);
     if (nsym == 0) return AETH_OK;
+    aeth::DeviceGuard dev_guard(ctx->device);
     AETH_REQUIRE(sym && bits, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(aeth::aligned8(sym) && ((uintptr_t)bits % (size_t)bps) == 0, AETH_E_ALIGN, "pointer alignment");
     if (bps == 1) hipLaunchKernelGGL(demod_kernel<1>, dim3(grid_for(nsym)), dim3(kBlock), 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);

@@ -69,6 +69,7 @@ int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal, size_t n, float power, uin
     AETH_REQUIRE(aeth::aligned8(signal), AETH_E_ALIGN, "signal not 8-byte aligned");
     AETH_REQUIRE(power >= 0.0f, AETH_E_ARG, "noise power must be >= 0");
     const float scale = sqrtf(power);                       // noise.rs:35
+    aeth::DeviceGuard dev_guard(ctx->device);
     const size_t pairs = (n + 1) / 2;
     hipLaunchKernelGGL(awgn_apply_kernel, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
                        reinterpret_cast<float2 *>(signal), n, scale, seed, offset, aeth::aligned16(signal) ? 1 : 0);

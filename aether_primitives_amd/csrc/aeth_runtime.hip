@@ -38,6 +38,7 @@ int tuning_int(const char *name, int dflt)
 
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes)
 {
+    DeviceGuard dev_guard(ctx->device);
     if (bytes == 0) bytes = 16;
     if (ctx->stage_bytes[i] < bytes) {
         size_t want = bytes + bytes / 4;
@@ -153,6 +154,7 @@ int aeth_dev_free(aeth_ctx *ctx, void *dptr)
 int aeth_upload(aeth_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    aeth::DeviceGuard dev_guard(ctx->device);
     if (bytes == 0) return AETH_OK;
     AETH_REQUIRE(dst_dev && src_host, AETH_E_ARG, "null pointer");
     AETH_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -163,6 +165,7 @@ int aeth_upload(aeth_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes
 int aeth_download(aeth_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    aeth::DeviceGuard dev_guard(ctx->device);
     if (bytes == 0) return AETH_OK;
     AETH_REQUIRE(dst_host && src_dev, AETH_E_ARG, "null pointer");
     AETH_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -173,6 +176,7 @@ int aeth_download(aeth_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
 int aeth_copy_dev(aeth_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    aeth::DeviceGuard dev_guard(ctx->device);
     if (bytes == 0) return AETH_OK;
     AETH_REQUIRE(dst_dev && src_dev, AETH_E_ARG, "null pointer");
     AETH_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));

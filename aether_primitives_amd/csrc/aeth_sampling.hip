@@ -148,6 +148,7 @@ int interpolate_impl(aeth_ctx *ctx, const aeth_cf32 *src, size_t S, size_t batch
     AETH_REQUIRE(nb < 0x7fffffffu, AETH_E_ARG, "n_between too large");
     if (batch == 0) return AETH_OK;
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
+    aeth::DeviceGuard dev_guard(ctx->device);
     AETH_REQUIRE(aeth::aligned8(src) && aeth::aligned8(dst), AETH_E_ALIGN, "pointer not 8-byte aligned");
     const size_t Lo = S + (S - 1) * nb;
     AETH_REQUIRE(cap >= Lo * batch, AETH_E_LEN, "dst capacity %zu < %zu", cap, Lo * batch);
@@ -218,6 +219,7 @@ int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, siz
     AETH_REQUIRE(((uintptr_t)src % elem) == 0 && ((uintptr_t)dst % elem) == 0, AETH_E_ALIGN,
                  "pointer not aligned to elem_size");
     const size_t dec = n_src / n_dst;
+    aeth::DeviceGuard dev_guard(ctx->device);
     const dim3 g(grid_for(ctx, n_dst)), b(kBlock);
     switch (elem) {
     case 1:  hipLaunchKernelGGL(downsample_kernel<uint8_t>,  g, b, 0, ctx->stream, (const uint8_t *)src,  (uint8_t *)dst,  n_dst, dec); break;

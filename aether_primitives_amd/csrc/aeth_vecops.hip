@@ -74,6 +74,7 @@ template <int OP>
 int launch_ew(aeth_ctx *ctx, aeth_cf32 *self, const aeth_cf32 *other, size_t n, float s)
 {
     if (n == 0) return AETH_OK;
+    aeth::DeviceGuard dev_guard(ctx->device);
     float2 *a = reinterpret_cast<float2 *>(self);
     const float2 *b = reinterpret_cast<const float2 *>(other);
     const bool two = reads_other<OP>();
@@ -119,6 +120,7 @@ int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch
 {
     const size_t mid = frame_len / 2;
     if (mid == 0 || batch == 0) return AETH_OK;
+    aeth::DeviceGuard dev_guard(ctx->device);
     float2 *x = reinterpret_cast<float2 *>(self);
     const bool vec = aeth::aligned16(x) && (mid % 2 == 0) && (frame_len % 2 == 0);
     if (vec) {
@@ -158,6 +160,7 @@ int host_roundtrip(aeth_ctx *ctx, aeth_cf32 *self, size_t n, const aeth_cf32 *ot
 {
     if (n == 0) return AETH_OK;
     const size_t bytes = n * sizeof(aeth_cf32);
+    aeth::DeviceGuard dev_guard(ctx->device);
     int rc = aeth::ctx_stage(ctx, 0, bytes);
     if (rc) return rc;
     if (other) { rc = aeth::ctx_stage(ctx, 1, bytes); if (rc) return rc; }

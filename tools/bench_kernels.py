@@ -2,6 +2,7 @@
 """Per-kernel bandwidth survey (HBM-honest sizes): every op of the hot path, achieved
 algorithmic GB/s against the 8 TB/s spec peak.  Rotates over buffers > Infinity Cache."""
 import os, sys, statistics, json
+os.environ.setdefault('AETH_TUNING', '1')
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aether_primitives_amd as ap
