@@ -51,16 +51,18 @@ class _Modulation:
     def symbol(self, idx):                                      # modulation.rs:13-15 / :26-28
         return self.table[idx]
 
-    def modulate(self, bits):                                   # modulation.rs:115-121
+    def modulate(self, bits, out=None):                         # modulation.rs:115-121 (out= : modulate_into, :124-131)
         if not isinstance(bits, DeviceBits):
             bits = DeviceBits(self.ctx, len(bits), bits)
-        out = DeviceVec(self.ctx, bits.n // self.BITS_PER_SYMBOL)
+        if out is None:
+            out = DeviceVec(self.ctx, bits.n // self.BITS_PER_SYMBOL)
         check(self._lib.aeth_modulate(self.ctx.h, C.c_void_p(bits.ptr), bits.n, self.BITS_PER_SYMBOL,
                                       self.table.ctypes.data_as(C.c_void_p), out._p(), out.n))
         return out
 
-    def demod_naive(self, symbols, compat=True):                # modulation.rs:33-56 / :133-144
-        out = DeviceBits(self.ctx, symbols.n * self.BITS_PER_SYMBOL)
+    def demod_naive(self, symbols, compat=True, out=None):      # modulation.rs:33-56 / :133-144
+        if out is None:
+            out = DeviceBits(self.ctx, symbols.n * self.BITS_PER_SYMBOL)
         check(self._lib.aeth_demod_naive(self.ctx.h, symbols._p(), symbols.n, self.BITS_PER_SYMBOL,
                                          self.table.ctypes.data_as(C.c_void_p), C.c_void_p(out.ptr), out.n,
                                          1 if compat else 0))

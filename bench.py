@@ -93,6 +93,53 @@ def measured_traffic():
     return best
 
 
+def side_workload(args):
+    """BASELINE configs 2, 4 and 5 on one GPU (device-resident, synthetic); same JSON shape, no roofline claim."""
+    import aether_primitives_amd as ap
+    from aether_primitives_amd import Scale, sampling, modulation, noise
+    ctx = ap.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    N = 2048
+    if args.workload == "c2":
+        n = 1 << 20                                             # 512 frames: 8 MiB, cache-resident by definition
+        f = ap.HipFft(ctx, N, max_batch=n // N)
+        bufs = [(ctx.vec(synth_stream(815 + i, n)), ctx.empty(n)) for i in range(4)]
+        def step(i):
+            a, b = bufs[i % 4]; f.fwd(a, b, Scale.SN); f.ifwd(a, Scale.SN)      # benches.rs:305-306,352-353
+        samples, name, bytes_ = 2 * n, "C2: FFT-2048 fwd (copy) + ifwd (in place) on a 1 Mi-sample stream", 32 * n
+    elif args.workload == "c5":
+        frames, nb = 64, 9
+        n = 65536 * frames
+        f = ap.HipFft(ctx, 65536, max_batch=frames)
+        bufs = [(ctx.vec(synth_stream(815 + i, n)), ctx.empty((65536 + 65535 * nb) * frames)) for i in range(3)]
+        def step(i):
+            a, o = bufs[i % 3]; f.ifwd(a, Scale.SN); sampling.interpolate(ctx, a, o, nb, frame_len=65536)
+        samples, name, bytes_ = n, "C5: 64 x 65536-point FFT (Scale::SN) + 10x linear interpolation", 104 * n
+    else:
+        frames = 4096
+        n = N * frames
+        rng = np.random.default_rng(815)
+        q = modulation.qpsk(ctx)
+        f = ap.HipFft(ctx, N, max_batch=frames)
+        ref = np.zeros(N, np.complex64); ref[:4] = np.conj(np.array([-1 + 1j, 0, 1 - 1j, 1 - 1j], np.complex64))
+        sig = ctx.vec(ref)
+        bits = [modulation.DeviceBits(ctx, 2 * n, rng.integers(0, 2, 2 * n, dtype=np.uint8)) for _ in range(2)]
+        awgn = noise.new(ctx, 0.01, 815)
+        txs = [ctx.empty(n) for _ in range(2)]
+        rxb = [modulation.DeviceBits(ctx, 2 * n) for _ in range(2)]
+        def step(i):
+            tx = q.modulate(bits[i % 2], out=txs[i % 2]); awgn.apply(tx); f.mul_chain(tx, sig)
+            q.demod_naive(tx, out=rxb[i % 2])
+        samples, name, bytes_ = n, "C4 (one channel): QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod, 4096 frames", 52 * n
+    for i in range(args.warmup): step(i)
+    ctx.sync(); t0 = time.perf_counter()
+    for i in range(args.steps): step(args.warmup + i)
+    ctx.sync(); el = time.perf_counter() - t0
+    print(json.dumps({"metric": "GSamples/s cf32", "value": round(samples * args.steps / el / 1e9, 3), "unit": "GSamples/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5),
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": name}, "algorithmic_GBps": round(bytes_ * args.steps / el / 1e9, 1)}), flush=True)
+
+
 def main():
     ap_ = argparse.ArgumentParser()
     ap_.add_argument("--gpus", type=int, default=1)
@@ -100,7 +147,11 @@ def main():
     ap_.add_argument("--warmup", type=int, default=20)
     ap_.add_argument("--streams", type=int, default=6, help="rotating working set, x 256 MiB (in+out) each")
     ap_.add_argument("--no-cpu-baseline", action="store_true")
+    ap_.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],
+                     help="c3 (default) = the headline config; the others are BASELINE configs 2, 4, 5 for the record")
     args = ap_.parse_args()
+    if args.workload != "c3":
+        return side_workload(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

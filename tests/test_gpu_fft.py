@@ -182,3 +182,37 @@ def test_fft_then_mirror_frames_is_fftshift(ctx, oracle):
     ref = ctx.vec(x); f.ifwd(ref, Scale.SN)
     exp = np.fft.fftshift(ref.to_host().reshape(frames, n), axes=1).reshape(-1)
     assert bits_equal(d.to_host(), exp)
+
+
+def test_c5_full_size_properties(ctx, oracle):
+    """BASELINE config 5: batched 65536-point FFT (Scale::SN) + 10x linear interpolation
+    (n_between = 9), 64 frames.  Oracle on a few frames, size-independent properties on all."""
+    from aether_primitives_amd import sampling
+    n, frames, nb = 65536, 64, 9
+    x = oracle.synth_cnormal(815, n * frames)
+    f = HipFft(ctx, n, max_batch=frames)
+    assert f.algorithm == "fourstep_pow2"
+    d = ctx.vec(x)
+    f.ifwd(d, Scale.SN)
+    X = d.to_host()
+    for fr in (0, 17, 63):                                   # oracle + f64 truth on single frames
+        seg = slice(fr * n, (fr + 1) * n)
+        truth = oracle.fft_f64(x[seg].astype(np.complex128), +1) / np.sqrt(float(n))
+        assert oracle.evm_db(X[seg], truth) <= TOL_DB
+    # Parseval on every frame
+    pin = (np.abs(x.astype(np.complex128)) ** 2).reshape(frames, n).sum(1)
+    pout = (np.abs(X.astype(np.complex128)) ** 2).reshape(frames, n).sum(1)
+    assert np.max(np.abs(pout / pin - 1)) < 1e-5
+    # round trip
+    back = ctx.vec(X); f.ibwd(back, Scale.SN)
+    assert oracle.evm_db(back.to_host(), x) <= TOL_DB
+    # interpolate every frame independently: 655351 outputs per frame, bit-exact vs the oracle on 3 frames,
+    # and the kept samples (every 10th output) must be the FFT outputs' real parts verbatim
+    Lo = n + (n - 1) * nb
+    out = ctx.empty(Lo * frames)
+    assert sampling.interpolate(ctx, d, out, nb, frame_len=n) == Lo * frames
+    Y = out.to_host().reshape(frames, Lo)
+    for fr in (0, 31, 63):
+        assert bits_equal(Y[fr], oracle.interpolate(X[fr * n:(fr + 1) * n], nb))
+    assert bits_equal(np.ascontiguousarray(Y[:, ::nb + 1].real), np.ascontiguousarray(X.reshape(frames, n).real))
+    assert bits_equal(np.ascontiguousarray(Y[:, -1]), np.ascontiguousarray(X.reshape(frames, n)[:, -1]))
