@@ -76,6 +76,7 @@ PROTOTYPES = {
     "aeth_fir_hop": (sz, [vp]),
     "aeth_fir_exec": (i32, [vp, vp, vp, sz, vp]),
     "aeth_fir_exec_host": (i32, [vp, vp, vp, sz, vp]),
+    "aeth_fir_stream_host": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),
     "aeth_interpolate_frames": (i32, [vp, vp, sz, sz, vp, sz, sz, i32, psz]),
     "aeth_host_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
 }
 
 template <class C, bool SCALED>
-int launch_fmi(aeth_ctx *ctx, const FmiArgs &a)
+int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
 {
     long long ngroups = (a.nblocks + C::F - 1) / C::F;
     long long cap = (long long)ctx->num_cus * 4;            // 2 waves/SIMD resident: 4 x 128-lane workgroups per CU
@@ -208,18 +208,19 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a)
     if (b.dbg & 4) b.twL = nullptr;
     const int g = aeth::tuning_int("AETH_FIR_GRID", 0);
     if (g > 0 && g < grid) grid = g;
-    hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1>), dim3(grid), dim3(C::WG), 0, ctx->stream, b);
+    hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1>), dim3(grid), dim3(C::WG), 0, stream, b);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
 
-int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a)
+int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = ctx->stream;
     aeth::DeviceGuard dev_guard(ctx->device);
     const bool scaled = !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
 #define AETH_BODY(NN)                                                            \
-    return scaled ? launch_fmi<typename CfgFor<NN>::type, true>(ctx, a)          \
-                  : launch_fmi<typename CfgFor<NN>::type, false>(ctx, a)
+    return scaled ? launch_fmi<typename CfgFor<NN>::type, true>(ctx, a, stream)  \
+                  : launch_fmi<typename CfgFor<NN>::type, false>(ctx, a, stream)
     AETH_POW2_SWITCH(fft_len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "fused FFT*H*IFFT: length %zu", fft_len))
 #undef AETH_BODY
 }
@@ -324,6 +325,104 @@ int aeth_fir_exec(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_
     a.nblocks = (long long)((n + f->hop - 1) / f->hop);
     a.s_fwd = 1.0f; a.s_bwd = 1.0f;
     return dispatch_fmi(f->ctx, f->fft_len, a);
+}
+
+}  // extern "C"
+
+namespace {
+
+int fir_exec_on(aeth_fir *f, hipStream_t stream, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out)
+{
+    FmiArgs a;
+    a.dbg = 0;
+    a.in = (const cf *)in; a.out = (cf *)out; a.hist = (const cf *)hist; a.Hf = (const cf *)f->Hf;
+    a.twN = (const cf *)f->fft->tw_dev; a.twL = (const cf *)f->fft->tw_lane_dev;
+    a.n = (long long)n; a.hop = (int)f->hop; a.ov = (int)(f->fft_len - f->hop); a.nhist = (int)(f->ntaps - 1);
+    a.nblocks = (long long)((n + f->hop - 1) / f->hop);
+    a.s_fwd = 1.0f; a.s_bwd = 1.0f;
+    return dispatch_fmi(f->ctx, f->fft_len, a, stream);
+}
+
+// Host-resident stream through the device in hop-aligned chunks, two slots in flight:
+// while slot A's chunk is being filtered, slot B's next chunk crosses PCIe one way and its
+// previous result the other.  The GPU-side counterpart of the reference's thread-per-stage
+// pipeline with pooled buffers (src/pipeline.rs:52-137, src/pool.rs:43-221) -- stages are
+// H2D copy | kernel | D2H copy on HIP streams, the pool is the pair of device slots.
+struct PipeSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    float2 *din = nullptr, *dout = nullptr;     // device: [history | chunk], chunk
+    bool busy = false;
+};
+
+}  // namespace
+
+extern "C" {
+
+int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
+{
+    AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
+    if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0};
+    if (n == 0) return AETH_OK;
+    AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(in != out, AETH_E_ARG, "FIR cannot run in place (blocks overlap)");
+    aeth_ctx *ctx = f->ctx;
+    aeth::DeviceGuard g(ctx->device);
+    const size_t nh = f->ntaps - 1;
+    if (chunk == 0) chunk = (size_t)4 << 20;                       // 32 MiB of samples per transfer
+    chunk = ((chunk + f->hop - 1) / f->hop) * f->hop;              // hop-aligned: same blocks as the one-shot run
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    // pin the caller's slices in place for true asynchronous copies (falls back to pageable copies)
+    const bool pin_in = hipHostRegister(const_cast<aeth_cf32 *>(in), n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
+    const bool pin_out = hipHostRegister(out, n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    PipeSlot slot[2];
+    int rc = AETH_OK;
+    auto fail = [&](hipError_t e, const char *what) { rc = aeth::hip_fail(e, what); };
+    for (int s = 0; s < 2 && rc == AETH_OK; s++) {
+        hipError_t e;
+        if ((e = hipStreamCreateWithFlags(&slot[s].stream, hipStreamNonBlocking)) != hipSuccess) { fail(e, "hipStreamCreate"); break; }
+        if ((e = hipEventCreateWithFlags(&slot[s].done, hipEventDisableTiming)) != hipSuccess) { fail(e, "hipEventCreate"); break; }
+        if ((e = hipMalloc((void **)&slot[s].din, (chunk + nh) * sizeof(float2))) != hipSuccess) { fail(e, "hipMalloc"); break; }
+        if ((e = hipMalloc((void **)&slot[s].dout, chunk * sizeof(float2))) != hipSuccess) { fail(e, "hipMalloc"); break; }
+    }
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (rc == AETH_OK) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipStreamSynchronize(ctx->stream); (void)hipEventRecord(t0, slot[0].stream); }
+    for (size_t k = 0; k < nchunks && rc == AETH_OK; k++) {
+        PipeSlot &sl = slot[k & 1];
+        const size_t o0 = k * chunk;
+        const size_t cnt = (n - o0 < chunk) ? n - o0 : chunk;
+        const size_t h = (o0 >= nh) ? nh : o0;                     // history samples available in the source
+        hipError_t e;
+        if (sl.busy && (e = hipEventSynchronize(sl.done)) != hipSuccess) { fail(e, "hipEventSynchronize"); break; }
+        // [zeros | history | chunk] -> device; the filter reads its history straight from the source slice
+        if (h < nh && (e = hipMemsetAsync(sl.din, 0, (nh - h) * sizeof(float2), sl.stream)) != hipSuccess) { fail(e, "hipMemsetAsync"); break; }
+        if ((e = hipMemcpyAsync(sl.din + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), hipMemcpyHostToDevice, sl.stream)) != hipSuccess) { fail(e, "hipMemcpyAsync H2D"); break; }
+        rc = fir_exec_on(f, sl.stream, o0 ? (const aeth_cf32 *)sl.din : nullptr, (const aeth_cf32 *)(sl.din + nh), cnt, (aeth_cf32 *)sl.dout);
+        if (rc) break;
+        if ((e = hipMemcpyAsync(out + o0, sl.dout, cnt * sizeof(float2), hipMemcpyDeviceToHost, sl.stream)) != hipSuccess) { fail(e, "hipMemcpyAsync D2H"); break; }
+        if ((e = hipEventRecord(sl.done, sl.stream)) != hipSuccess) { fail(e, "hipEventRecord"); break; }
+        sl.busy = true;
+    }
+    for (int s = 0; s < 2; s++) if (slot[s].stream) (void)hipStreamSynchronize(slot[s].stream);
+    if (rc == AETH_OK && stats && t0 && t1) {
+        // both slot streams are idle now; time from the first enqueue to here
+        (void)hipEventRecord(t1, slot[0].stream); (void)hipEventSynchronize(t1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1);
+        stats->seconds = ms * 1e-3; stats->samples = (double)n; stats->chunks = (double)nchunks;
+        stats->pinned = (pin_in ? 1 : 0) + (pin_out ? 2 : 0);
+    }
+    for (int s = 0; s < 2; s++) {
+        if (slot[s].din) (void)hipFree(slot[s].din);
+        if (slot[s].dout) (void)hipFree(slot[s].dout);
+        if (slot[s].done) (void)hipEventDestroy(slot[s].done);
+        if (slot[s].stream) (void)hipStreamDestroy(slot[s].stream);
+    }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    if (pin_in) (void)hipHostUnregister(const_cast<aeth_cf32 *>(in));
+    if (pin_out) (void)hipHostUnregister(out);
+    return rc;
 }
 
 int aeth_fir_exec_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out)

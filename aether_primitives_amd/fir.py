@@ -52,3 +52,17 @@ class Fir:
         check(self._lib.aeth_fir_exec_host(self.h, hp, x.ctypes.data_as(C.c_void_p), x.size,
                                            out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def filter_stream(self, x, out=None, chunk=0):
+        """Host array through the device in double-buffered hop-aligned chunks (PCIe-rate path).
+        Returns (y, stats) with stats = dict(seconds, samples, chunks, pinned)."""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        if out is None:
+            out = np.empty_like(x)
+
+        class _Stats(C.Structure):
+            _fields_ = [("seconds", C.c_double), ("samples", C.c_double), ("chunks", C.c_double), ("pinned", C.c_double)]
+        st = _Stats()
+        check(self._lib.aeth_fir_stream_host(self.h, x.ctypes.data_as(C.c_void_p), x.size,
+                                             out.ctypes.data_as(C.c_void_p), chunk, C.byref(st)))
+        return out, {"seconds": st.seconds, "samples": st.samples, "chunks": st.chunks, "pinned": st.pinned}

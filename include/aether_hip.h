@@ -182,6 +182,16 @@ AETH_API int aeth_fir_exec(aeth_fir *fir, const aeth_cf32 *hist_dev, const aeth_
 AETH_API int aeth_fir_exec_host(aeth_fir *fir, const aeth_cf32 *hist_host, const aeth_cf32 *in_host,
                                 size_t n, aeth_cf32 *out_host);
 
+/* Host-resident stream through the device at PCIe rate (SURVEY 8f "next" #4): hop-aligned
+ * chunks, two device slots on two HIP streams so that the H2D copy of chunk k+1, the kernel
+ * on chunk k and the D2H copy of chunk k-1 overlap -- the device-side counterpart of the
+ * reference's thread-per-stage pipeline over pooled buffers (src/pipeline.rs:52-137,
+ * src/pool.rs:43-221).  Output is bit-identical to aeth_fir_exec_host on the whole slice.
+ * chunk_samples = 0 picks 4 Mi samples.  stats may be NULL. */
+typedef struct { double seconds, samples, chunks, pinned; } aeth_pipe_stats;
+AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
+                                  size_t chunk_samples, aeth_pipe_stats *stats);
+
 /* ---- sampling: src/sampling.rs ---------------------------------------------- */
 /* interpolate (:7-24): writes n_src + (n_src-1)*n_between elements to dst
  * (the Rust wrapper reserves that much spare Vec capacity, passes its end, then
