@@ -77,6 +77,10 @@ PROTOTYPES = {
     "aeth_fir_exec": (i32, [vp, vp, vp, sz, vp]),
     "aeth_fir_exec_host": (i32, [vp, vp, vp, sz, vp]),
     "aeth_fir_stream_host": (i32, [vp, vp, sz, vp, sz, vp]),
+    "aeth_fir_stream_file": (i32, [vp, C.c_char_p, C.c_char_p, sz, vp]),
+    "aeth_file_count_structs": (i32, [C.c_char_p, sz, psz]),
+    "aeth_file_read": (i32, [C.c_char_p, sz, vp, sz, sz]),
+    "aeth_file_write": (i32, [C.c_char_p, vp, sz, sz, i32]),
     "aeth_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),
     "aeth_interpolate_frames": (i32, [vp, vp, sz, sz, vp, sz, sz, i32, psz]),
     "aeth_host_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),

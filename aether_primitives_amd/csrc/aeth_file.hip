@@ -1,0 +1,86 @@
+// aeth_file.hip -- raw sample files (reference: src/util/file.rs:12-107) and the
+// file -> device -> file FIR pipeline.  SURVEY 8f "next" rows #3 and #4.
+//
+// The reference's binary format is a header-less, native-endian dump of back-to-back
+// structs (BinaryWriter::write casts the slice to bytes, util/file.rs:101-109): for cf32
+// that is byte for byte the layout of a device buffer, so a recorded IQ stream can be
+// mapped and pushed through the GPU without any conversion.
+#include "aeth_internal.h"
+
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+extern "C" {
+
+/* count_structs_in_file (util/file.rs:12-25) */
+int aeth_file_count_structs(const char *path, size_t elem_size, size_t *count)
+{
+    AETH_REQUIRE(path && count && elem_size, AETH_E_ARG, "null/zero argument");
+    struct stat st;
+    AETH_REQUIRE(stat(path, &st) == 0, AETH_E_ARG, "%s: %s", path, strerror(errno));
+    AETH_REQUIRE((size_t)st.st_size % elem_size == 0, AETH_E_LEN,
+                 "File does not contain an integer number of the requested struct");   /* :20-23 */
+    *count = (size_t)st.st_size / elem_size;
+    return AETH_OK;
+}
+
+/* BinaryReader::read (util/file.rs:46-57): fill `n` structs starting at struct `offset` */
+int aeth_file_read(const char *path, size_t offset, void *dst, size_t n, size_t elem_size)
+{
+    AETH_REQUIRE(path && (dst || !n) && elem_size, AETH_E_ARG, "null/zero argument");
+    FILE *f = fopen(path, "rb");
+    AETH_REQUIRE(f, AETH_E_ARG, "%s: %s", path, strerror(errno));
+    int rc = AETH_OK;
+    if (fseeko(f, (off_t)(offset * elem_size), SEEK_SET) != 0 || fread(dst, elem_size, n, f) != n)
+        rc = aeth::set_error(AETH_E_LEN, "failed to fill whole buffer");               /* read_exact's UnexpectedEof */
+    fclose(f);
+    return rc;
+}
+
+/* binary_writer + BinaryWriter::write (util/file.rs:83-109): create/truncate unless append */
+int aeth_file_write(const char *path, const void *src, size_t n, size_t elem_size, int append)
+{
+    AETH_REQUIRE(path && (src || !n) && elem_size, AETH_E_ARG, "null/zero argument");
+    FILE *f = fopen(path, append ? "ab" : "wb");
+    AETH_REQUIRE(f, AETH_E_ARG, "%s: %s", path, strerror(errno));
+    int rc = AETH_OK;
+    if (fwrite(src, elem_size, n, f) != n) rc = aeth::set_error(AETH_E_ARG, "%s: short write", path);
+    if (fclose(f) != 0 && rc == AETH_OK) rc = aeth::set_error(AETH_E_ARG, "%s: %s", path, strerror(errno));
+    return rc;
+}
+
+/* raw cf32 file -> FIR -> raw cf32 file: both files are mapped and handed to the
+ * double-buffered host-stream pipeline (aeth_fir_stream_host) */
+int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_path, size_t chunk, aeth_pipe_stats *stats)
+{
+    AETH_REQUIRE(fir && in_path && out_path, AETH_E_ARG, "null argument");
+    size_t n = 0;
+    int rc = aeth_file_count_structs(in_path, sizeof(aeth_cf32), &n);
+    if (rc) return rc;
+    int fo = open(out_path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    AETH_REQUIRE(fo >= 0, AETH_E_ARG, "%s: %s", out_path, strerror(errno));
+    if (n == 0) { close(fo); if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0}; return AETH_OK; }
+    const size_t bytes = n * sizeof(aeth_cf32);
+    int fi = open(in_path, O_RDONLY);
+    void *mi = MAP_FAILED, *mo = MAP_FAILED;
+    if (fi < 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", in_path, strerror(errno));
+    if (rc == AETH_OK && ftruncate(fo, (off_t)bytes) != 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", out_path, strerror(errno));
+    if (rc == AETH_OK) {
+        mi = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fi, 0);
+        mo = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fo, 0);
+        if (mi == MAP_FAILED || mo == MAP_FAILED) rc = aeth::set_error(AETH_E_NOMEM, "mmap: %s", strerror(errno));
+    }
+    if (rc == AETH_OK) rc = aeth_fir_stream_host(fir, (const aeth_cf32 *)mi, n, (aeth_cf32 *)mo, chunk, stats);
+    if (mi != MAP_FAILED) munmap(mi, bytes);
+    if (mo != MAP_FAILED) { msync(mo, bytes, MS_SYNC); munmap(mo, bytes); }
+    if (fi >= 0) close(fi);
+    close(fo);
+    return rc;
+}
+
+}  // extern "C"

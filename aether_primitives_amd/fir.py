@@ -53,6 +53,16 @@ class Fir:
                                            out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def filter_file(self, in_path, out_path, chunk=0):
+        """raw cf32 file -> FIR -> raw cf32 file (util::file format), through the double-buffered pipeline."""
+        import os
+
+        class _Stats(C.Structure):
+            _fields_ = [("seconds", C.c_double), ("samples", C.c_double), ("chunks", C.c_double), ("pinned", C.c_double)]
+        st = _Stats()
+        check(self._lib.aeth_fir_stream_file(self.h, os.fsencode(in_path), os.fsencode(out_path), chunk, C.byref(st)))
+        return {"seconds": st.seconds, "samples": st.samples, "chunks": st.chunks, "pinned": st.pinned}
+
     def filter_stream(self, x, out=None, chunk=0):
         """Host array through the device in double-buffered hop-aligned chunks (PCIe-rate path).
         Returns (y, stats) with stats = dict(seconds, samples, chunks, pinned)."""

@@ -192,6 +192,16 @@ typedef struct { double seconds, samples, chunks, pinned; } aeth_pipe_stats;
 AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
                                   size_t chunk_samples, aeth_pipe_stats *stats);
 
+/* ---- raw sample files (SURVEY 8f "next" #3): src/util/file.rs:12-107 ------------------------ */
+/* The reference's binary files are header-less native-endian dumps of back-to-back structs;
+ * for cf32 that is exactly the byte layout of a device buffer. */
+AETH_API int aeth_file_count_structs(const char *path, size_t elem_size, size_t *count);            /* :12-25  */
+AETH_API int aeth_file_read(const char *path, size_t offset_structs, void *dst_host, size_t n, size_t elem_size);  /* BinaryReader::read :46-57 */
+AETH_API int aeth_file_write(const char *path, const void *src_host, size_t n, size_t elem_size, int append);      /* binary_writer + write :83-109 */
+/* raw cf32 file -> FIR -> raw cf32 file through the pipeline above (both files mapped) */
+AETH_API int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_path, size_t chunk_samples,
+                                  aeth_pipe_stats *stats);
+
 /* ---- sampling: src/sampling.rs ---------------------------------------------- */
 /* interpolate (:7-24): writes n_src + (n_src-1)*n_between elements to dst
  * (the Rust wrapper reserves that much spare Vec capacity, passes its end, then

@@ -1,0 +1,43 @@
+"""util::file restated behind the ABI (reference src/util/file.rs:12-107, tests :131-214):
+CPU tests (no device needed) + the file -> FIR -> file pipeline on the GPU."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, rand_c64
+
+
+def test_binary_roundtrip_and_struct_count(tmp_path):
+    from aether_primitives_amd import file as aefile, LengthMismatch
+    p = tmp_path / "samples.bin"
+    x = rand_c64(1, 1000)
+    w = aefile.binary_writer(p)
+    w.write(x[:400]); w.write(x[400:])                       # consecutive writes append to the stream
+    assert p.stat().st_size == 8000 and aefile.count_structs_in_file(p) == 1000
+    assert p.read_bytes() == x.tobytes()                     # header-less native-endian dump (file.rs:101-109)
+    r = aefile.binary_reader(p)
+    assert bits_equal(r.read_vec(250), x[:250]) and bits_equal(r.read(np.empty(750, np.complex64)), x[250:])
+    with pytest.raises(LengthMismatch):                      # read_exact past the end (file.rs:53)
+        r.read_vec(1)
+    (tmp_path / "odd.bin").write_bytes(b"\0" * 13)
+    with pytest.raises(LengthMismatch, match="integer number of the requested struct"):   # file.rs:20-23
+        aefile.count_structs_in_file(tmp_path / "odd.bin")
+    aefile.binary_writer(p)                                  # re-opening truncates (file.rs:86-88)
+    assert p.stat().st_size == 0
+    ints = np.arange(77, dtype=np.int32)
+    wi = aefile.binary_writer(tmp_path / "ints.bin", np.int32); wi.write(ints)
+    assert (aefile.binary_reader(tmp_path / "ints.bin", np.int32).read_vec(77) == ints).all()
+
+
+@pytest.mark.gpu
+def test_file_to_file_fir(ctx, oracle, tmp_path):
+    import aether_primitives_amd as ap
+    taps = oracle.synth_lowpass_taps(64, 0.25)
+    x = oracle.synth_cnormal(815, 3_000_001)
+    pin, pout = tmp_path / "in.bin", tmp_path / "out.bin"
+    ap.file.binary_writer(pin).write(x)
+    f = ap.Fir(ctx, taps, 2048)
+    st = f.filter_file(pin, pout, chunk=1 << 20)
+    assert st["samples"] == x.size and st["chunks"] == 3
+    y = ap.file.binary_reader(pout).read_vec(x.size)
+    assert bits_equal(y, f.filter(x))
+    assert oracle.evm_db(y, oracle.fir_ols_f32(taps, x, 2048, f.hop, threads=4)) <= -120
