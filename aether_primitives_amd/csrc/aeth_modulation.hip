@@ -15,42 +15,77 @@ struct Table4 { float2 s[4]; };
 const float2 kBpsk[2] = {{1.f, 1.f}, {-1.f, -1.f}};
 const float2 kQpsk[4] = {{1.f, 1.f}, {-1.f, 1.f}, {1.f, -1.f}, {-1.f, -1.f}};
 
-template <int BPS>
-__global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restrict__ bits, float2 *__restrict__ out,
-                                                          size_t nsym, Table4 t)
-{
-    const size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (s >= nsym) return;
-    unsigned idx;
-    if constexpr (BPS == 1) idx = bits[s] & 1u;                                   // modulation.rs:9-12
-    else {
-        const uchar2 b = reinterpret_cast<const uchar2 *>(bits)[s];
-        idx = ((b.y & 1u) << 1) + (b.x & 1u);                                     // modulation.rs:21-24
-    }
-    out[s] = t.s[idx];                                                            // modulation.rs:115-121
-}
+__device__ __forceinline__ unsigned qpsk_index(unsigned b0, unsigned b1) { return ((b1 & 1u) << 1) + (b0 & 1u); }   // modulation.rs:21-24
 
-template <int BPS>
-__global__ __launch_bounds__(kBlock) void demod_kernel(const float2 *__restrict__ sym, uint8_t *__restrict__ bits,
-                                                       size_t nsym, Table4 t, int compat)
+__device__ __forceinline__ unsigned nearest(float2 v, const Table4 &t, int ncand)
 {
-    const size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (s >= nsym) return;
-    const float2 v = sym[s];
     unsigned best = 0;
     float bd = 0.f;
 #pragma unroll
-    for (unsigned i = 0; i < (BPS == 1 ? 2u : 4u); i++) {
+    for (int i = 0; i < 4; i++) {
+        if (i >= ncand) break;
         const float dr = v.x - t.s[i].x, di = v.y - t.s[i].y;
         const float d = dr * dr + di * di;                                        // modulation.rs:36-41
-        if (i == 0 || d < bd) { best = i; bd = d; }                               // first minimum wins (:46-49)
+        if (i == 0 || d < bd) { best = (unsigned)i; bd = d; }                     // first minimum wins (:46-49)
     }
-    if constexpr (BPS == 1) bits[s] = (uint8_t)(best & 1u);                       // modulation.rs:143
-    else {
-        uchar2 o;
-        o.x = (uint8_t)(best & 1u);                                               // modulation.rs:53
-        o.y = (uint8_t)(compat ? (best & 2u) : ((best >> 1) & 1u));               // modulation.rs:54 (`idx & 1u8 << 1`)
-        reinterpret_cast<uchar2 *>(bits)[s] = o;
+    return best;
+}
+
+// Four input bytes and 16-byte stores per lane where the alignment allows (VEC): these
+// kernels move 10 B per symbol and are store- (modulate) or load-bound (demod).
+template <int BPS, bool VEC>
+__global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restrict__ bits, float2 *__restrict__ out,
+                                                          size_t nsym, Table4 t)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if constexpr (VEC) {
+        constexpr int SPL = 4 / BPS;                     // symbols per lane: 4 bytes of bits
+        const size_t s0 = i * SPL;
+        if (s0 >= nsym) return;
+        const uchar4 b = reinterpret_cast<const uchar4 *>(bits)[i];
+        if constexpr (BPS == 2) {
+            const float2 a = t.s[qpsk_index(b.x, b.y)], c = t.s[qpsk_index(b.z, b.w)];
+            reinterpret_cast<float4 *>(out)[i] = make_float4(a.x, a.y, c.x, c.y);
+        } else {
+            const float2 a = t.s[b.x & 1u], c = t.s[b.y & 1u], d = t.s[b.z & 1u], e = t.s[b.w & 1u];   // modulation.rs:9-12
+            reinterpret_cast<float4 *>(out)[2 * i] = make_float4(a.x, a.y, c.x, c.y);
+            reinterpret_cast<float4 *>(out)[2 * i + 1] = make_float4(d.x, d.y, e.x, e.y);
+        }
+    } else {
+        if (i >= nsym) return;
+        unsigned idx;
+        if constexpr (BPS == 1) idx = bits[i] & 1u;
+        else idx = qpsk_index(bits[2 * i], bits[2 * i + 1]);
+        out[i] = t.s[idx];                                                        // modulation.rs:115-121
+    }
+}
+
+template <int BPS, bool VEC>
+__global__ __launch_bounds__(kBlock) void demod_kernel(const float2 *__restrict__ sym, uint8_t *__restrict__ bits,
+                                                       size_t nsym, Table4 t, int compat)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    constexpr int NC = (BPS == 1) ? 2 : 4;              // trait default scans BITS_PER_SYMBOL*2 candidates (:135)
+    auto hi = [&](unsigned best) { return (uint8_t)(compat ? (best & 2u) : ((best >> 1) & 1u)); };   // modulation.rs:54
+    if constexpr (VEC) {
+        constexpr int SPL = 4 / BPS;
+        if (i * SPL >= nsym) return;
+        if constexpr (BPS == 2) {
+            const float4 v = reinterpret_cast<const float4 *>(sym)[i];
+            const unsigned a = nearest(make_float2(v.x, v.y), t, NC), c = nearest(make_float2(v.z, v.w), t, NC);
+            reinterpret_cast<uchar4 *>(bits)[i] = make_uchar4((uint8_t)(a & 1u), hi(a), (uint8_t)(c & 1u), hi(c));
+        } else {
+            const float4 v = reinterpret_cast<const float4 *>(sym)[2 * i], w = reinterpret_cast<const float4 *>(sym)[2 * i + 1];
+            reinterpret_cast<uchar4 *>(bits)[i] = make_uchar4((uint8_t)(nearest(make_float2(v.x, v.y), t, NC) & 1u),
+                                                              (uint8_t)(nearest(make_float2(v.z, v.w), t, NC) & 1u),
+                                                              (uint8_t)(nearest(make_float2(w.x, w.y), t, NC) & 1u),
+                                                              (uint8_t)(nearest(make_float2(w.z, w.w), t, NC) & 1u));   // :143
+        }
+    } else {
+        if (i >= nsym) return;
+        const unsigned best = nearest(sym[i], t, NC);
+        if constexpr (BPS == 1) bits[i] = (uint8_t)(best & 1u);
+        else { bits[2 * i] = (uint8_t)(best & 1u); bits[2 * i + 1] = hi(best); }  // modulation.rs:53-54
     }
 }
 
@@ -82,8 +117,13 @@ int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, con
     aeth::DeviceGuard dev_guard(ctx->device);
     AETH_REQUIRE(bits && out, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(aeth::aligned8(out) && ((uintptr_t)bits % (size_t)bps) == 0, AETH_E_ALIGN, "pointer alignment");
-    if (bps == 1) hipLaunchKernelGGL(modulate_kernel<1>, dim3(grid_for(n_out)), dim3(kBlock), 0, ctx->stream, bits, (float2 *)out, n_out, t);
-    else          hipLaunchKernelGGL(modulate_kernel<2>, dim3(grid_for(n_out)), dim3(kBlock), 0, ctx->stream, bits, (float2 *)out, n_out, t);
+    const size_t spl = 4 / (size_t)bps;
+    const bool vec = aeth::aligned16(out) && ((uintptr_t)bits % 4) == 0 && (n_out % spl) == 0;
+    const dim3 gv(grid_for(n_out / spl)), gs(grid_for(n_out)), b(kBlock);
+    if (bps == 1 && vec)       hipLaunchKernelGGL((modulate_kernel<1, true>),  gv, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
+    else if (bps == 1)         hipLaunchKernelGGL((modulate_kernel<1, false>), gs, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
+    else if (vec)              hipLaunchKernelGGL((modulate_kernel<2, true>),  gv, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
+    else                       hipLaunchKernelGGL((modulate_kernel<2, false>), gs, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -99,8 +139,13 @@ int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym, size_t nsym, int bps, 
     aeth::DeviceGuard dev_guard(ctx->device);
     AETH_REQUIRE(sym && bits, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(aeth::aligned8(sym) && ((uintptr_t)bits % (size_t)bps) == 0, AETH_E_ALIGN, "pointer alignment");
-    if (bps == 1) hipLaunchKernelGGL(demod_kernel<1>, dim3(grid_for(nsym)), dim3(kBlock), 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
-    else          hipLaunchKernelGGL(demod_kernel<2>, dim3(grid_for(nsym)), dim3(kBlock), 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
+    const size_t spl = 4 / (size_t)bps;
+    const bool vec = aeth::aligned16(sym) && ((uintptr_t)bits % 4) == 0 && (nsym % spl) == 0;
+    const dim3 gv(grid_for(nsym / spl)), gs(grid_for(nsym)), b(kBlock);
+    if (bps == 1 && vec)       hipLaunchKernelGGL((demod_kernel<1, true>),  gv, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
+    else if (bps == 1)         hipLaunchKernelGGL((demod_kernel<1, false>), gs, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
+    else if (vec)              hipLaunchKernelGGL((demod_kernel<2, true>),  gv, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
+    else                       hipLaunchKernelGGL((demod_kernel<2, false>), gs, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

@@ -75,4 +75,14 @@ for dec in (2, 8, 30):
     report(f"downsample dec={dec} (n_dst={nd})", 16 * nd, timeit(lambda i: sampling.downsample(ctx, A[i % NB].slice(0, nd * dec), d)), nd)
 small = ctx.vec(host[:30720]); d1 = ctx.empty(1024)
 report("downsample 30720->1024 (reference bench shape)", 16 * 1024, timeit(lambda i: sampling.downsample(ctx, small, d1), reps=100), 1024)
+# modulation / noise
+from aether_primitives_amd import modulation, noise
+nsym = 1 << 25
+q = modulation.qpsk(ctx)
+bits = modulation.DeviceBits(ctx, 2 * nsym, rng.integers(0, 2, 2 * nsym, dtype=np.uint8))
+outb = modulation.DeviceBits(ctx, 2 * nsym)
+report("qpsk modulate 2^25 symbols", 10 * nsym, timeit(lambda i: q.modulate(bits, out=A[i % NB])), nsym)
+report("qpsk demod_naive 2^25 symbols", 10 * nsym, timeit(lambda i: q.demod_naive(A[i % NB], out=outb)), nsym)
+g = noise.new(ctx, 0.01, 815)
+report("awgn apply 2^25 samples", 16 * nsym, timeit(lambda i: g.apply(A[i % NB])), nsym)
 json.dump(rows, open("gpurun_out/kernel_survey.json", "w"), indent=1)
