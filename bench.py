@@ -156,7 +156,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
+        # one rank per GPU: the process count is the truth (for N > 1 launch through
+        # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`)
+        if rank == 0 and args.gpus != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
         args.gpus = world
 
     import torch
