@@ -1,0 +1,166 @@
+"""GPU parity at sizes whose BYTE offsets cross 4 GiB (and, for interpolate, whose element
+count crosses 2^31): the "maximum sizes" edge of the path.  288 GB of HBM makes such
+operands ordinary, and 32-bit index arithmetic in a kernel would only show here.
+
+The operands are built on the device by tiling a 2^22-sample seeded pattern (no multi-GiB
+host arrays); results are checked on slices -- the head, the 4 GiB crossing, the ragged
+tail -- against the oracle run on the same slice.  Element-wise ops bit-exact
+(src/vecops.rs:94-177, src/sampling.rs:7-42); FFT/FIR within the -80 dB aggregate EVM
+of the headline metric (src/lib.rs:26-49).
+"""
+import numpy as np
+import pytest
+
+import aether_primitives_amd as ap
+from aether_primitives_amd import Scale, sampling
+from helpers import bits_equal, rand_c64
+
+pytestmark = pytest.mark.gpu
+
+P = 1 << 22                       # pattern period (samples)
+CROSS = 1 << 29                   # sample index whose byte offset is 4 GiB
+
+
+def tiled(ctx, pattern_dev, n):
+    """DeviceVec of n samples = the pattern repeated (device-to-device clones)."""
+    v = ctx.empty(n)
+    for o in range(0, n, P):
+        m = min(P, n - o)
+        v.slice(o, o + m).vec_clone(pattern_dev.slice(0, m))
+    return v
+
+
+def host_slice(pat, lo, hi):
+    idx = np.arange(lo, hi) % P
+    return pat[idx]
+
+
+def windows(n, w=4096):
+    """(lo, hi) slices worth checking for an n-sample vector"""
+    out = [(0, w), (CROSS - w, min(CROSS + w, n)), (max(n - w, 0), n)]
+    return [(lo, hi) for lo, hi in out if 0 <= lo < hi <= n]
+
+
+@pytest.mark.parametrize("op", ["vec_add", "vec_mul", "vec_div", "vec_conj", "vec_scale", "vec_mirror"])
+def test_vecops_beyond_4gib(ctx, oracle, op):
+    n = CROSS + (1 << 20) + 3
+    pa, pb = rand_c64(11, P), rand_c64(12, P) + np.complex64(3)
+    da, db = ctx.vec(pa), ctx.vec(pb)
+    a = tiled(ctx, da, n)
+    b = tiled(ctx, db, n) if op in ("vec_add", "vec_mul", "vec_div") else None
+    if op == "vec_scale": a.vec_scale(0.37)
+    elif b is not None: getattr(a, op)(b)
+    else: getattr(a, op)()
+    ctx.sync()
+    mid = n // 2
+    for lo, hi in windows(n):
+        got = a.slice(lo, hi).to_host()
+        if op == "vec_mirror":
+            # swap(x, x+mid): output[i] = input[i+mid] for i < mid, input[i-mid] above (vecops.rs:157-161);
+            # an odd length leaves the last element in place
+            idx = np.arange(lo, hi)
+            src = np.where(idx < mid, idx + mid, idx - mid)
+            if n % 2: src = np.where(idx == n - 1, idx, src)
+            want = pa[src % P]
+        else:
+            x = host_slice(pa, lo, hi).copy()
+            if op == "vec_scale": want = oracle.vec_scale(x, 0.37)
+            elif op == "vec_conj": want = oracle.vec_conj(x)
+            else: want = getattr(oracle, op)(x, host_slice(pb, lo, hi))
+        assert bits_equal(got, want), (op, lo, hi)
+
+
+def test_fft2048_batch_beyond_4gib(ctx, oracle):
+    N = 2048
+    batch = CROSS // N + 5                       # frames straddle the 4 GiB byte offset
+    pat = rand_c64(21, P)
+    x = tiled(ctx, ctx.vec(pat), N * batch)
+    f = ap.HipFft(ctx, N)
+    f.ifwd(x, Scale.SN)
+    ctx.sync()
+    cf = oracle.Cfft(N)
+    for fr in (0, CROSS // N - 1, CROSS // N, batch - 1):
+        got = x.slice(fr * N, (fr + 1) * N).to_host()
+        ref = oracle.fft_f64(host_slice(pat, fr * N, (fr + 1) * N).astype(np.complex128), +1) / np.sqrt(N)
+        assert oracle.evm_db(got, ref) <= -80.0, fr
+        assert oracle.evm_db(got, cf.fwd(host_slice(pat, fr * N, (fr + 1) * N), 1)) <= -80.0, fr
+    # round trip of the whole buffer returns the pattern (checked on slices)
+    f.ibwd(x, Scale.SN)
+    ctx.sync()
+    for lo, hi in windows(N * batch):
+        assert oracle.evm_db(x.slice(lo, hi).to_host(), host_slice(pat, lo, hi)) <= -80.0
+
+
+def test_fir_stream_beyond_4gib(ctx, oracle):
+    n = CROSS + 3 * 1984 + 17
+    taps = oracle.synth_lowpass_taps(64, 0.25)
+    pat = rand_c64(31, P)
+    x = tiled(ctx, ctx.vec(pat), n)
+    y = ctx.empty(n)
+    fir = ap.Fir(ctx, taps, 2048)
+    fir.filter(x, out=y)
+    ctx.sync()
+    for lo, hi in windows(n, 8192):
+        h0 = max(lo - 63, 0)
+        seg = host_slice(pat, h0, hi)
+        ref = oracle.fir_direct_f64(taps, seg)[lo - h0:]
+        got = y.slice(lo, hi).to_host()
+        if lo == 0:
+            ref = oracle.fir_direct_f64(taps, host_slice(pat, 0, hi))
+        assert oracle.evm_db(got, ref) <= -80.0, (lo, hi)
+
+
+def test_interpolate_output_beyond_4gib(ctx, oracle):
+    # 32-bit-index kernel with byte offsets past 4 GiB: 2^26+1 inputs x 9 between -> ~2^29.3 outputs
+    S = (1 << 26) + 1
+    nb = 9
+    pat = rand_c64(41, P)
+    src = tiled(ctx, ctx.vec(pat), S)
+    Lo = S + (S - 1) * nb
+    dst = ctx.empty(Lo)
+    assert sampling.interpolate(ctx, src, dst, nb) == Lo
+    ctx.sync()
+    for w0 in (0, (CROSS // (nb + 1)) - 50, S - 200):
+        w1 = min(w0 + 200, S)
+        want = oracle.interpolate(host_slice(pat, w0, w1), nb)
+        # the oracle closes its slice with the raw last sample (sampling.rs:22-23); inside the
+        # stream that position is an ordinary i = 0 output, so it is compared only at the true end
+        k = want.size if w1 == S else want.size - 1
+        got = dst.slice(w0 * (nb + 1), w0 * (nb + 1) + k).to_host()
+        assert bits_equal(got, want[:k]), w0
+
+
+def test_interpolate_beyond_2_31_outputs(ctx, oracle):
+    # more than 2^31 outputs (16 GiB): the 64-bit kernel
+    S = (1 << 27) + 7
+    nb = 16
+    pat = rand_c64(42, P)
+    src = tiled(ctx, ctx.vec(pat), S)
+    Lo = S + (S - 1) * nb
+    assert Lo > (1 << 31)
+    dst = ctx.empty(Lo)
+    assert sampling.interpolate(ctx, src, dst, nb) == Lo
+    ctx.sync()
+    for w0 in (0, (1 << 31) // (nb + 1) - 50, (1 << 32) // (nb + 1) - 50 if (1 << 32) < Lo else 1000, S - 150):
+        w1 = min(w0 + 150, S)
+        want = oracle.interpolate(host_slice(pat, w0, w1), nb)
+        # the oracle closes its slice with the raw last sample (sampling.rs:22-23); inside the
+        # stream that position is an ordinary i = 0 output, so it is compared only at the true end
+        k = want.size if w1 == S else want.size - 1
+        got = dst.slice(w0 * (nb + 1), w0 * (nb + 1) + k).to_host()
+        assert bits_equal(got, want[:k]), w0
+
+
+def test_downsample_source_beyond_4gib(ctx, oracle):
+    n_dst = (1 << 24) + 1
+    dec = 40
+    n_src = n_dst * dec                         # 5.4 GiB of source
+    pat = rand_c64(51, P)
+    src = tiled(ctx, ctx.vec(pat), n_src)
+    dst = ctx.empty(n_dst)
+    sampling.downsample(ctx, src, dst)
+    ctx.sync()
+    for lo in (0, CROSS // dec - 100, n_dst - 300):
+        hi = min(lo + 300, n_dst)
+        want = pat[(np.arange(lo, hi) * dec) % P]
+        assert bits_equal(dst.slice(lo, hi).to_host(), want), lo
