@@ -18,7 +18,7 @@ def one(pattern):
     return f[-1] if f else None
 
 
-out = {"tag": tag, "command": "python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"}
+out = {"tag": tag, "command": "python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline"}
 st = one("trace/*/*_kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
@@ -35,7 +35,7 @@ for key, pat in (("FETCH_SIZE", "fetch/*/*_counter_collection.csv"), ("WRITE_SIZ
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
             if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == key]
     if vals:
-        vals = vals[len(vals) // 10:]          # drop warm-up launches
+        vals = vals[-2000:]                    # the timed launches (settle + warm-up come first)
         out[key + "_KiB_per_launch_raw"] = sum(vals) / len(vals)
 for name in ("trace", "fetch", "write"):
     p = os.path.join(src, f"{name}_bench.json")
@@ -52,5 +52,25 @@ if "FETCH_SIZE_KiB_per_launch_raw" in out and "WRITE_SIZE_KiB_per_launch_raw" in
     out["hbm_bytes_per_launch"] = rd + wr
     out["algorithmic_bytes_per_launch"] = 16 * (1 << 24)
     out["traffic_over_algorithmic"] = (rd + wr) / (16 * (1 << 24))
+# per-dispatch duration over the run: shows the load-onset power transient and the settled state
+tr = one("trace/*/*_kernel_trace.csv")
+if tr:
+    rows = [r for r in csv.DictReader(open(tr)) if KERNEL in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if rows:
+        t0 = int(rows[0]["Start_Timestamp"])
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        timed = durs[-2000:]
+        out["timed_launches_avg_us"] = sum(timed) / len(timed)
+        out["timed_launches_min_us"] = min(timed)
+        out["timed_launches_max_us"] = max(timed)
+        pts = [{"launch": i, "t_ms": round((int(r["Start_Timestamp"]) - t0) / 1e6, 3), "dur_us": round(durs[i], 2)}
+               for i, r in enumerate(rows) if i < 40 or i % 25 == 0]
+        json.dump({"note": "per-dispatch duration of fmi_kernel over one bench run (rocprofv3 --kernel-trace, "
+                           "python3 bench.py --steps 2000 --warmup 200): ~2 ms at full speed after the idle gap, "
+                           "then 10-25 % slower for ~25 ms while the power management settles, then steady; "
+                           "bench.py's untimed settle phase + warm-up cover the transient, the last 2000 "
+                           "dispatches are the timed region", "dispatches": pts},
+                  open(f"profiles/{tag}_fmi_duration_vs_time.json", "w"))
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("bench_line")}, indent=1))
