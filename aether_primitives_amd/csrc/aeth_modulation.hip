@@ -17,6 +17,15 @@ const float2 kQpsk[4] = {{1.f, 1.f}, {-1.f, 1.f}, {1.f, -1.f}, {-1.f, -1.f}};
 
 __device__ __forceinline__ unsigned qpsk_index(unsigned b0, unsigned b1) { return ((b1 & 1u) << 1) + (b0 & 1u); }   // modulation.rs:21-24
 
+// table[idx] by selects on the (scalar-register) entries: a runtime index into the by-value table
+// would turn into a second, dependent global load from the kernarg segment per symbol
+__device__ __forceinline__ float2 pick(const Table4 &t, unsigned idx)
+{
+    const bool b0 = idx & 1u, b1 = idx & 2u;
+    const float2 lo = b0 ? t.s[1] : t.s[0], hi = b0 ? t.s[3] : t.s[2];
+    return b1 ? hi : lo;
+}
+
 __device__ __forceinline__ unsigned nearest(float2 v, const Table4 &t, int ncand)
 {
     unsigned best = 0;
@@ -44,10 +53,10 @@ __global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restr
         if (s0 >= nsym) return;
         const uchar4 b = reinterpret_cast<const uchar4 *>(bits)[i];
         if constexpr (BPS == 2) {
-            const float2 a = t.s[qpsk_index(b.x, b.y)], c = t.s[qpsk_index(b.z, b.w)];
+            const float2 a = pick(t, qpsk_index(b.x, b.y)), c = pick(t, qpsk_index(b.z, b.w));
             reinterpret_cast<float4 *>(out)[i] = make_float4(a.x, a.y, c.x, c.y);
         } else {
-            const float2 a = t.s[b.x & 1u], c = t.s[b.y & 1u], d = t.s[b.z & 1u], e = t.s[b.w & 1u];   // modulation.rs:9-12
+            const float2 a = pick(t, b.x & 1u), c = pick(t, b.y & 1u), d = pick(t, b.z & 1u), e = pick(t, b.w & 1u);   // modulation.rs:9-12
             reinterpret_cast<float4 *>(out)[2 * i] = make_float4(a.x, a.y, c.x, c.y);
             reinterpret_cast<float4 *>(out)[2 * i + 1] = make_float4(d.x, d.y, e.x, e.y);
         }
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restr
         unsigned idx;
         if constexpr (BPS == 1) idx = bits[i] & 1u;
         else idx = qpsk_index(bits[2 * i], bits[2 * i + 1]);
-        out[i] = t.s[idx];                                                        // modulation.rs:115-121
+        out[i] = pick(t, idx);                                                    // modulation.rs:115-121
     }
 }
 

@@ -12,7 +12,14 @@ ctx = ap.Context(0)
 e0, e1 = ctx.event(), ctx.event()
 
 
-def timeit(fn, reps=20, rounds=5):
+def timeit(fn, reps=20, rounds=5, settle_ms=40.0):
+    # carry the device through its load-onset power transient first (tools/transient.py): a kernel that
+    # draws more than the previous one runs 10-25 % slower for ~25 ms before it settles
+    import time
+    t0 = time.perf_counter(); k = 0
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        for i in range(10): fn(k + i)
+        k += 10; ctx.sync()
     ts = []
     for _ in range(rounds):
         fn(0); fn(1); ctx.sync(); e0.record()
