@@ -164,10 +164,18 @@ int plan_pow2(aeth_fft *plan)
 constexpr int kMixedWG = 256;
 constexpr int kMaxFactors = 16;
 
+// One Stockham pass: m = n/R butterflies of radix R, p = product of the radices before it.
+struct MixedPass {
+    int R, p, m;
+    int tw_off;                 // this pass's twiddles in the plan's pass table: [(r-1)*p + k] = W_{pR}^{rk}
+    aeth::FastDiv pdiv;         // i / p by multiply-high
+};
+
 struct MixedDesc {
     int n;
     int nfac;
-    int fac[kMaxFactors];
+    int stage;                  // 1: copy the frame to LDS first (single pass, or a generic prime radix in front)
+    MixedPass pass[kMaxFactors];
 };
 
 __device__ __forceinline__ cf tw_at(const cf *__restrict__ twN, int idx) { return twN[idx]; }
@@ -230,10 +238,88 @@ __device__ __forceinline__ void bfly7(cf (&u)[7], const cf *__restrict__ twN, in
     }
 }
 
+template <int R>
+__device__ __forceinline__ void mixed_bfly(cf (&u)[R], const cf *__restrict__ twN, int n)
+{
+    if constexpr (R == 3) bfly3(u[0], u[1], u[2]);
+    else if constexpr (R == 5) bfly5(u[0], u[1], u[2], u[3], u[4]);
+    else if constexpr (R == 7) bfly7(u, twN, n);
+    else Bfly<R, -1>::run(u);
+}
+
+// One pass with a compile-time radix.  The first pass reads the frame straight from global
+// memory (unless staged), the last one writes it back; both are coalesced (lane i touches
+// element i + r*m resp. i + r*p with p = m in the last pass).  Twiddles come from the plan's
+// per-pass table, contiguous in k, so adjacent lanes read adjacent entries.
+template <int R, bool SWAP>
+__device__ __forceinline__ void mixed_pass(const MixedPass &ps, int n, int lane, int tpf, bool from_global,
+                                           bool to_global, bool active, const cf *gin, cf *gout, const cf *X, cf *Y,
+                                           const cf *twP, const cf *__restrict__ twN, float scale)
+{
+    const int m = ps.m, p = ps.p;
+    const cf *tw = twP + ps.tw_off;
+    for (int i = lane; i < m; i += tpf) {
+        const int k = i - (int)aeth::fdiv((uint32_t)i, ps.pdiv) * p;
+        const int j = (i - k) * R + k;
+        cf u[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            cf v;
+            if (from_global) { v = active ? gin[i + r * m] : mk(0.f, 0.f); if (SWAP) v = cswap(v); }
+            else v = X[i + r * m];
+            u[r] = v;
+        }
+        if (p > 1) {
+#pragma unroll
+            for (int r = 1; r < R; r++) u[r] = cmul_plain(u[r], tw[(r - 1) * p + k]);
+        }
+        mixed_bfly<R>(u, twN, n);
+        if (to_global) {
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    cf v = cscale(u[r], scale);
+                    gout[j + r * p] = SWAP ? cswap(v) : v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) Y[j + r * p] = u[r];
+        }
+    }
+}
+
+// generic prime radix (11 .. 61): O(R^2), inputs re-read from LDS (always staged or behind another pass)
 template <bool SWAP>
-__global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *out,
-                                                              const cf *__restrict__ twN, MixedDesc d,
-                                                              size_t batch, float scale, int tpf)
+__device__ __forceinline__ void mixed_pass_prime(const MixedPass &ps, int n, int lane, int tpf, bool to_global,
+                                                 bool active, cf *gout, const cf *X, cf *Y,
+                                                 const cf *twP, const cf *__restrict__ twN, float scale)
+{
+    const int R = ps.R, m = ps.m, p = ps.p;
+    const cf *tw = twP + ps.tw_off;
+    const int rstep = n / R;
+    for (int i = lane; i < m; i += tpf) {
+        const int k = i - (int)aeth::fdiv((uint32_t)i, ps.pdiv) * p;
+        const int j = (i - k) * R + k;
+        auto ld = [&](int r) -> cf {
+            cf v = X[i + r * m];
+            return (p > 1 && r > 0) ? cmul_plain(v, tw[(r - 1) * p + k]) : v;
+        };
+        for (int q = 0; q < R; q++) {
+            cf acc = ld(0);
+            for (int r = 1; r < R; r++) acc = cadd_plain(acc, cmul_plain(ld(r), twN[((r * q) % R) * rstep]));
+            if (to_global) {
+                acc = cscale(acc, scale);
+                if (active) gout[j + q * p] = SWAP ? cswap(acc) : acc;
+            } else Y[j + q * p] = acc;
+        }
+    }
+}
+
+template <bool SWAP>
+__global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *out, const cf *__restrict__ twN,
+                                                              const cf *twP, MixedDesc d, size_t batch,
+                                                              float scale, int tpf, int tw_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // tpf lanes per frame, kMixedWG / tpf frames per workgroup (small lengths would leave
@@ -244,89 +330,50 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
     const int lane = threadIdx.x % tpf;
     cf *bufA = reinterpret_cast<cf *>(smem_raw) + (size_t)fl * 2 * n;
     cf *bufB = bufA + n;
+    if (tw_lds) {
+        // the pass twiddles sit behind the frame images: an LDS read per factor instead of a global one
+        cf *t = reinterpret_cast<cf *>(smem_raw) + (size_t)fpw * 2 * n;
+        for (int e = threadIdx.x; e < tw_lds; e += kMixedWG) t[e] = twP[e];
+        twP = t;
+    }
     const size_t ngroups = (batch + fpw - 1) / fpw;
     for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const size_t frame = grp * fpw + fl;
         const bool active = frame < batch;
         const cf *gin = in + frame * (size_t)n;
         cf *gout = out + frame * (size_t)n;
-        // stage the frame (lets every pass read LDS; keeps in-place launches safe)
-        __syncthreads();
-        for (int e = lane; e < n; e += tpf) {
-            cf v = active ? gin[e] : mk(0.f, 0.f);
-            bufA[e] = SWAP ? cswap(v) : v;
-        }
-        __syncthreads();
+        __syncthreads();                                   // the previous group's last pass is done with LDS
         if (d.nfac == 0) {      // len == 1: the DFT is the identity
-            for (int e = lane; e < n; e += tpf) {
-                cf v = cscale(bufA[e], scale);
-                if (active) gout[e] = SWAP ? cswap(v) : v;
-            }
+            if (active && lane == 0) gout[0] = cscale(gin[0], scale);
             continue;
         }
         cf *X = bufA, *Y = bufB;
-        int p = 1;
-        for (int s = 0; s < d.nfac; s++) {
-            const int R = d.fac[s];
-            const int m = n / R;
-            const int step = n / (p * R);
-            const bool last = (s == d.nfac - 1);
-            for (int i = lane; i < m; i += tpf) {
-                const int k = i % p;
-                const int j = (i - k) * R + k;
-                auto ld = [&](int r) -> cf {
-                    cf v = X[i + r * m];
-                    return (p > 1 && r > 0) ? cmul_plain(v, twN[r * k * step]) : v;
-                };
-                auto st = [&](int r, cf v) {
-                    if (last) {
-                        v = cscale(v, scale);
-                        if (active) gout[j + r * p] = SWAP ? cswap(v) : v;
-                    } else Y[j + r * p] = v;
-                };
-                if (R == 2) {
-                    cf u[2] = {ld(0), ld(1)};
-                    Bfly<2, -1>::run(u);
-                    st(0, u[0]); st(1, u[1]);
-                } else if (R == 4) {
-                    cf u[4] = {ld(0), ld(1), ld(2), ld(3)};
-                    Bfly<4, -1>::run(u);
-                    st(0, u[0]); st(1, u[1]); st(2, u[2]); st(3, u[3]);
-                } else if (R == 8) {
-                    cf u[8];
-#pragma unroll
-                    for (int r = 0; r < 8; r++) u[r] = ld(r);
-                    Bfly<8, -1>::run(u);
-#pragma unroll
-                    for (int r = 0; r < 8; r++) st(r, u[r]);
-                } else if (R == 3) {
-                    cf a = ld(0), b = ld(1), c = ld(2);
-                    bfly3(a, b, c);
-                    st(0, a); st(1, b); st(2, c);
-                } else if (R == 5) {
-                    cf a = ld(0), b = ld(1), c = ld(2), e = ld(3), f = ld(4);
-                    bfly5(a, b, c, e, f);
-                    st(0, a); st(1, b); st(2, c); st(3, e); st(4, f);
-                } else if (R == 7) {
-                    cf u[7];
-#pragma unroll
-                    for (int r = 0; r < 7; r++) u[r] = ld(r);
-                    bfly7(u, twN, n);
-#pragma unroll
-                    for (int r = 0; r < 7; r++) st(r, u[r]);
-                } else {
-                    // generic prime radix: O(R^2), inputs re-read from LDS
-                    const int rstep = n / R;
-                    for (int q = 0; q < R; q++) {
-                        cf acc = ld(0);
-                        for (int r = 1; r < R; r++) acc = cadd_plain(acc, cmul_plain(ld(r), twN[((r * q) % R) * rstep]));
-                        st(q, acc);
-                    }
-                }
+        if (d.stage) {
+            // single pass (every lane reads what other lanes overwrite) or a prime radix in front
+            // (re-reads its inputs R times): the frame goes to LDS first
+            for (int e = lane; e < n; e += tpf) {
+                cf v = active ? gin[e] : mk(0.f, 0.f);
+                bufB[e] = SWAP ? cswap(v) : v;
             }
             __syncthreads();
+            X = bufB; Y = bufA;
+        }
+        for (int s = 0; s < d.nfac; s++) {
+            const MixedPass &ps = d.pass[s];
+            const bool fg = (s == 0) && !d.stage, tg = (s == d.nfac - 1);
+#define AETH_PASS(RR) mixed_pass<RR, SWAP>(ps, n, lane, tpf, fg, tg, active, gin, gout, X, Y, twP, twN, scale)
+            switch (ps.R) {
+            case 2: AETH_PASS(2); break;
+            case 3: AETH_PASS(3); break;
+            case 4: AETH_PASS(4); break;
+            case 5: AETH_PASS(5); break;
+            case 7: AETH_PASS(7); break;
+            case 8: AETH_PASS(8); break;
+            default: mixed_pass_prime<SWAP>(ps, n, lane, tpf, tg, active, gout, X, Y, twP, twN, scale); break;
+            }
+#undef AETH_PASS
+            __syncthreads();
             cf *t = X; X = Y; Y = t;
-            p *= R;
         }
     }
 }
@@ -337,10 +384,20 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
     MixedDesc d;
     d.n = (int)plan->len;
     d.nfac = (int)plan->factors.size();
-    for (int i = 0; i < d.nfac; i++) d.fac[i] = plan->factors[i];
+    int pp = 1, off = 0;
+    for (int i = 0; i < d.nfac; i++) {
+        MixedPass &ps = d.pass[i];
+        ps.R = plan->factors[i]; ps.p = pp; ps.m = d.n / ps.R;
+        ps.pdiv = aeth::make_fastdiv((uint32_t)pp);
+        ps.tw_off = off;
+        if (pp > 1) off += (ps.R - 1) * pp;
+        pp *= ps.R;
+    }
+    auto small_radix = [](int r) { return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8; };
+    d.stage = (d.nfac == 1 || (d.nfac > 0 && !small_radix(d.pass[0].R))) ? 1 : 0;
     // lanes per frame: the widest pass (N / smallest radix butterflies), rounded up to a power of two
-    int minr = d.nfac ? d.fac[0] : 1;
-    for (int i = 1; i < d.nfac; i++) if (d.fac[i] < minr) minr = d.fac[i];
+    int minr = d.nfac ? d.pass[0].R : 1;
+    for (int i = 1; i < d.nfac; i++) if (d.pass[i].R < minr) minr = d.pass[i].R;
     int need = d.nfac ? (d.n + minr - 1) / minr : d.n, tpf = 1;
     while (tpf < need && tpf < kMixedWG) tpf <<= 1;
     // two LDS images per frame; keep a workgroup under 64 KiB
@@ -350,11 +407,16 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
     size_t cap = (size_t)ctx->num_cus * 8;
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
-    const size_t shmem = (size_t)fpw * 2 * plan->len * sizeof(cf);
+    size_t shmem = (size_t)fpw * 2 * plan->len * sizeof(cf);
+    int tw_lds = 0;
+    if (off > 0 && shmem + (size_t)off * sizeof(cf) <= 40 * 1024) {     // keeps >= 4 workgroups per CU
+        tw_lds = off;
+        shmem += (size_t)off * sizeof(cf);
+    }
     if (sign > 0)
-        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale, tpf);
+        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds);
     else
-        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, d, batch, scale, tpf);
+        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -384,6 +446,31 @@ int make_twiddles(aeth_ctx *ctx, size_t n, float2 **out_dev)
     AETH_HIP(hipMalloc((void **)out_dev, h.size() * sizeof(float2)));
     AETH_HIP(hipMemcpyAsync(*out_dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     AETH_HIP(hipStreamSynchronize(ctx->stream));
+    return AETH_OK;
+}
+
+// per-pass twiddle tables of stockham_mixed: pass s (radix R, p = product of the radices before it)
+// multiplies input r of butterfly k by W_{pR}^{rk}; stored [(r-1)*p + k] so adjacent lanes read adjacent
+// entries.  Angles are formed in double from the exact integer r*k, like the master table.
+int plan_mixed(aeth_fft *plan)
+{
+    std::vector<float2> h;
+    size_t pp = 1;
+    for (int R : plan->factors) {
+        if (pp > 1) {
+            const double base = -2.0 * M_PI / (double)(pp * (size_t)R);
+            for (int r = 1; r < R; r++)
+                for (size_t k = 0; k < pp; k++) {
+                    const double a = base * (double)((size_t)r * k);
+                    h.push_back(make_float2((float)cos(a), (float)sin(a)));
+                }
+        }
+        pp *= (size_t)R;
+    }
+    if (h.empty()) h.push_back(make_float2(1.f, 0.f));
+    AETH_HIP(hipMalloc((void **)&plan->tw_pass_dev, h.size() * sizeof(float2)));
+    AETH_HIP(hipMemcpyAsync(plan->tw_pass_dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, plan->ctx->stream));
+    AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
     return AETH_OK;
 }
 
@@ -457,6 +544,7 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     }
     if (rc == AETH_OK) rc = make_twiddles(ctx, len, &p->tw_dev);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_POW2) rc = plan_pow2(p);
+    if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_MIXED) rc = plan_mixed(p);
     if (rc == AETH_OK) rc = aeth::fft_ensure_tmp(p, 2 * len * max_batch);
     if (rc == AETH_OK) {
         hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * len * sizeof(float2), hipHostMallocDefault);
@@ -475,6 +563,7 @@ int aeth_fft_destroy(aeth_fft *p)
     aeth::fft_plan_release_children(p);
     if (p->tw_dev) (void)hipFree(p->tw_dev);
     if (p->tw_lane_dev) (void)hipFree(p->tw_lane_dev);
+    if (p->tw_pass_dev) (void)hipFree(p->tw_pass_dev);
     if (p->tmp_dev) (void)hipFree(p->tmp_dev);
     if (p->tmp_host) (void)hipHostFree(p->tmp_host);
     delete p;

@@ -13,6 +13,7 @@ struct aeth_fft {
     const char *algo_name = "";
     float2 *tw_dev = nullptr;        // exp(-2 pi i k / len), k < len
     float2 *tw_lane_dev = nullptr;   // stockham_pow2: per-lane twiddle registers, [slot][lane]
+    float2 *tw_pass_dev = nullptr;   // stockham_mixed: per-pass twiddles, contiguous in the butterfly index
     float2 *tmp_dev = nullptr;       // >= 2*len*max_batch (Cfft.tmp, fft.rs:141,155)
     size_t tmp_elems = 0;
     float2 *tmp_host = nullptr;      // pinned 2*len: what tfwd/tbwd lend out

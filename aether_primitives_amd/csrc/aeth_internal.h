@@ -37,6 +37,28 @@ int tuning_int(const char *name, int dflt);
 inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// n / d for 32-bit n by multiply-high and shifts (Granlund-Montgomery round-up form):
+// index arithmetic of store-bound kernels must not cost more than their stores.
+struct FastDiv {
+    uint32_t d, m, sh1, sh2;
+};
+inline FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f)
+{
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;

@@ -11,6 +11,10 @@
 
 namespace {
 
+using aeth::FastDiv;
+using aeth::make_fastdiv;
+using aeth::fdiv;
+
 constexpr int kBlock = 256;
 
 // Linear interpolation, frames of S inputs -> frames of Lo = S + (S-1)*nb outputs.
@@ -25,28 +29,6 @@ constexpr int kBlock = 256;
 // sample of a frame is a pseudo-window with zero rates (sampling.rs:23).
 constexpr int kChunks = 4;                      // 16-byte stores per lane
 constexpr int kOutPerWG = 2 * kBlock * kChunks; // outputs per workgroup: amortises the load -> LDS -> store latency chain
-
-// n / d for 32-bit n by multiply-high and shifts (Granlund-Montgomery round-up form):
-// the index arithmetic of this store-bound kernel must not cost more than its stores.
-struct FastDiv {
-    uint32_t d, m, sh1, sh2;
-};
-inline FastDiv make_fastdiv(uint32_t d)
-{
-    FastDiv f;
-    f.d = d;
-    uint32_t l = 0;
-    while ((1ull << l) < d) l++;
-    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
-    f.sh1 = l < 1 ? l : 1;
-    f.sh2 = l > 0 ? l - 1 : 0;
-    return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f)
-{
-    const uint32_t t = __umulhi(f.m, n);
-    return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
 
 // 32-bit index version (total < 2^31): the common case
 __global__ __launch_bounds__(kBlock) void interpolate_kernel32(const float2 *__restrict__ src, float2 *__restrict__ dst,
