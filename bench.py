@@ -93,11 +93,69 @@ def measured_traffic():
     return best
 
 
+class Ranks:
+    """One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE); RCCL is used for the
+    barrier and the MAX-over-ranks of the elapsed time only -- the data path has no exchange step."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            # the process count is the truth (for N > 1 launch through
+            # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`)
+            if self.rank == 0 and args.gpus != 1:
+                print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; reporting n_gpus={self.world}", file=sys.stderr)
+            args.gpus = self.world
+        import torch
+        self.torch = torch
+        self.dist = None
+        if self.world > 1 or "RANK" in os.environ:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+
+    def barrier(self, ctx):
+        if self.dist is not None:
+            t = self.torch.zeros(1, device="cuda")
+            self.dist.all_reduce(t)
+        self.torch.cuda.synchronize()
+        ctx.sync()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], device="cuda", dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def settle(step, ctx, ms):
+    """Untimed launches of `step` for `ms` milliseconds: carries the device through its load-onset power
+    transient (tools/transient.py: after >= 5 ms of idle ~2 ms at full speed, then 10-25 % slower for
+    ~25 ms, then steady).  Returns the number of launches."""
+    n, t0 = 0, time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for i in range(50):
+            step(n + i)
+        n += 50
+        ctx.sync()
+    return n
+
+
 def side_workload(args):
-    """BASELINE configs 2, 4 and 5 on one GPU (device-resident, synthetic); same JSON shape, no roofline claim."""
+    """BASELINE configs 2, 4 and 5 (device-resident, synthetic); same JSON shape, no roofline claim.
+    Under torch.distributed.run every rank runs its own channel (C4) / frame shard (C2, C5) on its own GPU."""
+    ranks = Ranks(args)
     import aether_primitives_amd as ap
     from aether_primitives_amd import Scale, sampling, modulation, noise
-    ctx = ap.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    ctx = ap.Context(ranks.local_rank)
     N = 2048
     if args.workload == "c2":
         n = 1 << 20                                             # 512 frames: 8 MiB, cache-resident by definition
@@ -117,27 +175,33 @@ def side_workload(args):
     else:
         frames = 4096
         n = N * frames
-        rng = np.random.default_rng(815)
+        rng = np.random.default_rng(815 + ranks.rank)       # one independent channel per rank
         q = modulation.qpsk(ctx)
         f = ap.HipFft(ctx, N, max_batch=frames)
         ref = np.zeros(N, np.complex64); ref[:4] = np.conj(np.array([-1 + 1j, 0, 1 - 1j, 1 - 1j], np.complex64))
         sig = ctx.vec(ref)
         bits = [modulation.DeviceBits(ctx, 2 * n, rng.integers(0, 2, 2 * n, dtype=np.uint8)) for _ in range(2)]
-        awgn = noise.new(ctx, 0.01, 815)
+        awgn = noise.new(ctx, 0.01, 815 + ranks.rank)
         txs = [ctx.empty(n) for _ in range(2)]
         rxb = [modulation.DeviceBits(ctx, 2 * n) for _ in range(2)]
         def step(i):
             tx = q.modulate(bits[i % 2], out=txs[i % 2]); awgn.apply(tx); f.mul_chain(tx, sig)
             q.demod_naive(tx, out=rxb[i % 2])
-        samples, name, bytes_ = n, "C4 (one channel): QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod, 4096 frames", 52 * n
+        samples, name, bytes_ = n, "C4 (one channel per GPU): QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod, 4096 frames", 52 * n
+    ranks.barrier(ctx)
+    nsettle = settle(step, ctx, args.settle_ms)
     for i in range(args.warmup): step(i)
-    ctx.sync(); t0 = time.perf_counter()
+    ranks.barrier(ctx); t0 = time.perf_counter()
     for i in range(args.steps): step(args.warmup + i)
-    ctx.sync(); el = time.perf_counter() - t0
-    print(json.dumps({"metric": "GSamples/s cf32", "value": round(samples * args.steps / el / 1e9, 3), "unit": "GSamples/s",
-                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 5),
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": name}, "algorithmic_GBps": round(bytes_ * args.steps / el / 1e9, 1)}), flush=True)
+    ctx.sync(); el = ranks.max_over_ranks(time.perf_counter() - t0)
+    if ranks.rank == 0:
+        print(json.dumps({"metric": "GSamples/s cf32", "value": round(samples * args.steps * args.gpus / el / 1e9, 3),
+                          "unit": "GSamples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "settle_launches": nsettle, "ms_per_step": round(el / args.steps * 1e3, 5),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": name},
+                          "algorithmic_GBps_per_gpu": round(bytes_ * args.steps / el / 1e9, 1)}), flush=True)
+    ranks.close()
 
 
 def main():
@@ -156,23 +220,8 @@ def main():
     if args.workload != "c3":
         return side_workload(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        # one rank per GPU: the process count is the truth (for N > 1 launch through
-        # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`)
-        if rank == 0 and args.gpus != 1:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-        args.gpus = world
-
-    import torch
-    dist = None
-    if world > 1 or "RANK" in os.environ:                 # launched by torch.distributed.run: one rank per GPU
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ranks = Ranks(args)
+    rank, local_rank = ranks.rank, ranks.local_rank
 
     import aether_primitives_amd as ap
     ctx = ap.Context(local_rank)
@@ -188,24 +237,14 @@ def main():
         fir.filter(ins[i % nstreams], out=outs[i % nstreams])
 
     def barrier():
-        if dist is not None:
-            t = torch.zeros(1, device="cuda")
-            dist.all_reduce(t)
-        torch.cuda.synchronize()
-        ctx.sync()
+        ranks.barrier(ctx)
 
     ev0, ev1 = ctx.event(), ctx.event()
     barrier()                  # RCCL sets its communicator up lazily: have that idle gap here, not next to the timed region
     # Load-onset transient: after >= 5 ms of idle the GPU runs ~2 ms at full speed, then 10-25 % slower for
     # ~25 ms while its power management settles (profiles/r01_fmi_duration_vs_time.json).  A stream processor
     # lives in the settled state, so reach it before the warm-up; nothing below is skipped or shortened.
-    settle = 0
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-        for i in range(50):
-            step(settle + i)
-        settle += 50
-        ctx.sync()
+    nsettle = settle(step, ctx, args.settle_ms)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -215,15 +254,12 @@ def main():
         step(args.warmup + i)
     ev1.record()
     ctx.sync()
-    torch.cuda.synchronize()
+    ranks.torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kern_ms = ev0.elapsed_ms(ev1) / max(args.steps, 1)       # per launch, on the kernel's own stream
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        barrier()
+    elapsed = ranks.max_over_ranks(elapsed)
+    barrier()
 
     if rank == 0:
         total_samples = float(STREAM) * args.steps * args.gpus
@@ -232,7 +268,7 @@ def main():
         line = {
             "metric": "GSamples/s cf32 (FFT-2048 + 64-tap FIR chain)",
             "value": round(value, 3), "unit": "GSamples/s", "n_gpus": args.gpus, "steps": args.steps,
-            "warmup": args.warmup, "settle_launches": settle, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "warmup": args.warmup, "settle_launches": nsettle, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C3: 64-tap FIR via overlap-save (FFT-2048) on 16 Mi cf32 samples per step "
@@ -252,8 +288,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
 
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
