@@ -260,6 +260,16 @@ def main():
     kern_ms = ev0.elapsed_ms(ev1) / max(args.steps, 1)       # per launch, on the kernel's own stream
     elapsed = ranks.max_over_ranks(elapsed)
     barrier()
+    # a plain device copy of the same bytes, same buffers, right behind the timed region (the
+    # fraction is reported against the spec peak AND against what a copy reaches on this device)
+    c0, c1 = ctx.event(), ctx.event()
+    for i in range(20):
+        outs[i % nstreams].vec_clone(ins[i % nstreams])
+    c0.record()
+    for i in range(200):
+        outs[i % nstreams].vec_clone(ins[i % nstreams])
+    c1.record(); ctx.sync()
+    copy_gbs = BYTES_PER_SAMPLE * STREAM / (c0.elapsed_ms(c1) / 200 * 1e-3) / 1e9
 
     if rank == 0:
         total_samples = float(STREAM) * args.steps * args.gpus
@@ -278,6 +288,7 @@ def main():
                        "parallelism": f"{args.gpus} independent stream(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
                          "traffic": (measured_traffic() or (None, None))[1],
                          "traffic_source": (measured_traffic() or (None, None))[0],
                          "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>>", "kernel_ms": round(kern_ms, 5),
