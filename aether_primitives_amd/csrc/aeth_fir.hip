@@ -16,8 +16,8 @@
 // transform's last pass leaves the spectrum in exactly the register slots the
 // inverse transform's first pass reads, so the multiply by H happens in registers
 // with no exchange.  H and the twiddles live in registers across a persistent
-// loop over blocks.  hop is rounded down to a multiple of 64 samples so that every
-// block's window and output start on a 512-byte boundary.
+// loop over blocks.  For windows of 512 samples and more hop is rounded down to a multiple of
+// 64 samples so that every block's window and output start on a 512-byte boundary.
 #include "aeth_internal.h"
 #include "aeth_fft_core.h"
 #include "aeth_fft_plan.h"
@@ -273,8 +273,12 @@ int aeth_fir_create(aeth_ctx *ctx, const aeth_cf32 *taps, size_t ntaps, size_t f
     aeth_fir *f = new (std::nothrow) aeth_fir();
     AETH_REQUIRE(f, AETH_E_NOMEM, "out of host memory");
     f->ctx = ctx; f->ntaps = ntaps; f->fft_len = fft_len;
+    // outputs per block: the one-frame-per-workgroup lengths round it down to 64 samples so that every
+    // window and output block starts on a 512-byte boundary (descriptor loads, full lines); the short
+    // windows, several to a workgroup, are bound by the block count and keep every output they can
+    // (measured: fft_len 64, 8 taps: hop 57 -> 170 GS/s, hop 48 -> 155 GS/s)
     size_t L = fft_len - ntaps + 1;
-    f->hop = (L >= 64) ? (L / 64) * 64 : L;
+    f->hop = (fft_len >= 512 && L >= 64) ? (L / 64) * 64 : L;
     int rc = aeth_fft_create(ctx, fft_len, 1, &f->fft);
     if (rc == AETH_OK) {
         hipError_t e = hipMalloc((void **)&f->Hf, fft_len * sizeof(float2));
