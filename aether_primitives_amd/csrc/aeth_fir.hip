@@ -200,7 +200,8 @@ template <class C, bool SCALED>
 int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
 {
     long long ngroups = (a.nblocks + C::F - 1) / C::F;
-    long long cap = (long long)ctx->num_cus * 4;            // 2 waves/SIMD resident: 4 x 128-lane workgroups per CU
+    // persistent grid = what is resident at once: the kernel's ~230 VGPRs allow 2 waves per SIMD, 8 per CU
+    long long cap = (long long)ctx->num_cus * 8 / (C::WG / 64);
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
     FmiArgs b = a;
