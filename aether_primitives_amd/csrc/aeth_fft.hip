@@ -137,7 +137,7 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
 int dispatch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
 #define AETH_BODY(NN) return launch_pow2<typename CfgFor<NN>::type>(plan, in, out, batch, sign, scale)
-    AETH_POW2_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
+    AETH_POW2_SWITCH_XL(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
 #undef AETH_BODY
 }
 
@@ -156,7 +156,7 @@ int build_lane_table(aeth_fft *plan)
 int plan_pow2(aeth_fft *plan)
 {
 #define AETH_BODY(NN) return build_lane_table<typename CfgFor<NN>::type>(plan)
-    AETH_POW2_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
+    AETH_POW2_SWITCH_XL(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
 #undef AETH_BODY
 }
 
@@ -527,7 +527,7 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
         p->algo = aeth::FFT_ALGO_MIXED;      // zero passes: copy + scale
         p->factors.clear();
         p->algo_name = "identity";
-    } else if (is_pow2(len) && len <= 4096) {
+    } else if (is_pow2(len) && len <= 8192) {
         p->algo = aeth::FFT_ALGO_POW2;
         p->algo_name = "stockham_pow2";
     } else if (len <= 4096 && factorize_mixed(len, p->factors)) {

@@ -462,6 +462,9 @@ template <> struct CfgFor<512>  { using type = Cfg<512, 8, 8, 8, 8>; };
 template <> struct CfgFor<1024> { using type = Cfg<1024, 16, 16, 16, 4>; };
 template <> struct CfgFor<2048> { using type = Cfg<2048, 16, 16, 16, 8>; };
 template <> struct CfgFor<4096> { using type = Cfg<4096, 16, 16, 16, 16>; };
+// 8192: the largest frame whose padded LDS image (68 KiB) and 512 lanes x 16 points still leave the
+// register prefetch stage room at 2 waves per SIMD; plain transforms only (AETH_POW2_SWITCH_XL)
+template <> struct CfgFor<8192> { using type = Cfg<8192, 16, 16, 16, 8, 4>; };
 
 // expands BODY(N) for the runtime length `len` (power of two, 2..4096)
 #define AETH_POW2_SWITCH(len, BODY, DEFAULT)                                            \
@@ -470,6 +473,16 @@ template <> struct CfgFor<4096> { using type = Cfg<4096, 16, 16, 16, 16>; };
     case 32: BODY(32); case 64: BODY(64); case 128: BODY(128); case 256: BODY(256);    \
     case 512: BODY(512); case 1024: BODY(1024); case 2048: BODY(2048);                 \
     case 4096: BODY(4096);                                                             \
+    default: DEFAULT;                                                                  \
+    }
+
+// the same plus the lengths only the plain transform kernels are built for
+#define AETH_POW2_SWITCH_XL(len, BODY, DEFAULT)                                         \
+    switch (len) {                                                                     \
+    case 2: BODY(2); case 4: BODY(4); case 8: BODY(8); case 16: BODY(16);              \
+    case 32: BODY(32); case 64: BODY(64); case 128: BODY(128); case 256: BODY(256);    \
+    case 512: BODY(512); case 1024: BODY(1024); case 2048: BODY(2048);                 \
+    case 4096: BODY(4096); case 8192: BODY(8192);                                      \
     default: DEFAULT;                                                                  \
     }
 

@@ -243,8 +243,8 @@ int aeth_fft_mul_ifft(aeth_fft *plan, aeth_cf32 *frames, size_t n_total, size_t 
     if (batch == 0) return AETH_OK;
     AETH_REQUIRE(frames && sig, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(aeth::aligned8(frames) && aeth::aligned8(sig), AETH_E_ALIGN, "pointer not 8-byte aligned");
-    if (plan->algo != aeth::FFT_ALGO_POW2) {
-        // generic lengths: the three trait calls, unfused
+    if (plan->algo != aeth::FFT_ALGO_POW2 || plan->len > 4096) {
+        // generic lengths (and the 8192-point frame, too wide for the fused kernel's registers): the three trait calls, unfused
         int rc = aeth_fft_exec(plan, frames, n_total, frames, batch, AETH_SIGN_REF_FWD, kind_fwd, x_fwd);
         if (rc) return rc;
         for (size_t f = 0; f < batch && rc == AETH_OK; f++)

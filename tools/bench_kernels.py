@@ -66,7 +66,7 @@ for N in (8192, 65536, 1 << 20):
     f2 = ap.HipFft(ctx, N)
     for bt in ((64, n // N) if N == 65536 else (n // N,)):
         m = bt * N
-        report(f"fft ifwd N={N} batch={bt} (four-step)", 16 * m, timeit(lambda i: f2.ifwd(A[i % NB].slice(0, m), Scale.SN)), m)
+        report(f"fft ifwd N={N} batch={bt} ({f2.algorithm})", 16 * m, timeit(lambda i: f2.ifwd(A[i % NB].slice(0, m), Scale.SN)), m)
 f3 = ap.HipFft(ctx, 4099)
 m = (n // 4099 // 8) * 4099
 report(f"fft ifwd N=4099 batch={m // 4099} (bluestein)", 16 * m, timeit(lambda i: f3.ifwd(A[i % NB].slice(0, m), Scale.SN), reps=5), m)
