@@ -24,6 +24,10 @@
 
 using namespace aeth::fftk;
 
+#ifndef AETH_4S_LDS_LIMIT
+#define AETH_4S_LDS_LIMIT (144 * 1024)
+#endif
+
 namespace {
 
 // single LDS image regardless of size (the column/row kernels hold G frames per workgroup)
@@ -40,7 +44,7 @@ template <class C> constexpr int group_of()
 {
     // frames per workgroup: 16 for 128-byte segments, fewer when lanes or LDS run out
     int g = 16;
-    while (g > 1 && (g * C::T > 1024 || g * col_stride<C>() * 8 > 64 * 1024)) g /= 2;
+    while (g > 1 && (g * C::T > 1024 || g * col_stride<C>() * 8 > AETH_4S_LDS_LIMIT || C::N * (g + 1) * 8 > AETH_4S_LDS_LIMIT)) g /= 2;
     return g;
 }
 

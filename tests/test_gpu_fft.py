@@ -21,7 +21,7 @@ TOL_DB = -120.0
 
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 MIXED = [1, 3, 5, 6, 7, 9, 10, 12, 15, 20, 25, 49, 60, 61, 100, 120, 210, 1000, 1155, 3125, 4095]
-BIG = [8192, 16384, 65536, 1 << 18]
+BIG = [8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
 
 
