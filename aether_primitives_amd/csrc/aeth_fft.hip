@@ -530,7 +530,7 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     } else if (is_pow2(len) && len <= 8192) {
         p->algo = aeth::FFT_ALGO_POW2;
         p->algo_name = "stockham_pow2";
-    } else if (len <= 4096 && factorize_mixed(len, p->factors)) {
+    } else if (len <= 8192 && factorize_mixed(len, p->factors)) {      // two LDS images of the frame: 128 KiB at most
         p->algo = aeth::FFT_ALGO_MIXED;
         p->algo_name = "stockham_mixed";
     } else if (is_pow2(len)) {
