@@ -395,13 +395,22 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
     }
     auto small_radix = [](int r) { return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8; };
     d.stage = (d.nfac == 1 || (d.nfac > 0 && !small_radix(d.pass[0].R))) ? 1 : 0;
-    // lanes per frame: the widest pass (N / smallest radix butterflies), rounded up to a power of two
+    // Lanes per frame.  These kernels are latency-bound (a chain of short passes with a barrier each), so
+    // what counts is how many frames a CU has in flight, and the number of workgroups per CU is capped by
+    // registers (~6).  So: as many frames per workgroup as ~36 KiB of LDS images allow (4-5 workgroups
+    // per CU), each lane looping over its frame's butterflies, but never more lanes than the widest pass
+    // has butterflies (N / smallest radix) and at least 8.
     int minr = d.nfac ? d.pass[0].R : 1;
     for (int i = 1; i < d.nfac; i++) if (d.pass[i].R < minr) minr = d.pass[i].R;
-    int need = d.nfac ? (d.n + minr - 1) / minr : d.n, tpf = 1;
-    while (tpf < need && tpf < kMixedWG) tpf <<= 1;
-    // two LDS images per frame; keep a workgroup under 64 KiB
-    while (tpf < kMixedWG && (size_t)(kMixedWG / tpf) * 2 * plan->len * sizeof(cf) > 64 * 1024) tpf <<= 1;
+    const int need = d.nfac ? (d.n + minr - 1) / minr : d.n;
+    int tpf = aeth::tuning_int("AETH_MIXED_TPF", 0);
+    if (tpf < 1 || tpf > kMixedWG || (tpf & (tpf - 1))) {
+        int widest = 1;
+        while (widest < need && widest < kMixedWG) widest <<= 1;
+        tpf = widest < 8 ? widest : 8;
+        // the LDS bound is the hard one (a frame of 4097..8192 samples takes one workgroup and up to 128 KiB)
+        while (tpf < kMixedWG && (size_t)(kMixedWG / tpf) * 2 * plan->len * sizeof(cf) > 36 * 1024) tpf <<= 1;
+    }
     const int fpw = kMixedWG / tpf;
     const size_t ngroups = (batch + fpw - 1) / fpw;
     size_t cap = (size_t)ctx->num_cus * 8;
