@@ -251,17 +251,14 @@ __device__ __forceinline__ void mixed_bfly(cf (&u)[R], const cf *__restrict__ tw
 // memory (unless staged), the last one writes it back; both are coalesced (lane i touches
 // element i + r*m resp. i + r*p with p = m in the last pass).  Twiddles come from the plan's
 // per-pass table, contiguous in k, so adjacent lanes read adjacent entries.
-template <int R, bool SWAP>
+template <int R, bool SWAP, int PTS>
 __device__ __forceinline__ void mixed_pass(const MixedPass &ps, int n, int lane, int tpf, bool from_global,
                                            bool to_global, bool active, const cf *gin, cf *gout, const cf *X, cf *Y,
                                            const cf *twP, const cf *__restrict__ twN, float scale)
 {
     const int m = ps.m, p = ps.p;
     const cf *tw = twP + ps.tw_off;
-    for (int i = lane; i < m; i += tpf) {
-        const int k = i - (int)aeth::fdiv((uint32_t)i, ps.pdiv) * p;
-        const int j = (i - k) * R + k;
-        cf u[R];
+    auto load = [&](cf (&u)[R], int i) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             cf v;
@@ -269,6 +266,10 @@ __device__ __forceinline__ void mixed_pass(const MixedPass &ps, int n, int lane,
             else v = X[i + r * m];
             u[r] = v;
         }
+    };
+    auto finish = [&](cf (&u)[R], int i) {
+        const int k = i - (int)aeth::fdiv((uint32_t)i, ps.pdiv) * p;
+        const int j = (i - k) * R + k;
         if (p > 1) {
 #pragma unroll
             for (int r = 1; r < R; r++) u[r] = cmul_plain(u[r], tw[(r - 1) * p + k]);
@@ -285,6 +286,30 @@ __device__ __forceinline__ void mixed_pass(const MixedPass &ps, int n, int lane,
         } else {
 #pragma unroll
             for (int r = 0; r < R; r++) Y[j + r * p] = u[r];
+        }
+    };
+    if constexpr (PTS == 0) {
+        for (int i = lane; i < m; i += tpf) {
+            cf u[R];
+            load(u, i);
+            finish(u, i);
+        }
+    } else {
+        // ONE LDS image per frame (Y == X): a lane first pulls every input of all its butterflies into
+        // registers (n / tpf <= PTS points), the workgroup meets, then the outputs overwrite the image.
+        // Twice the frames in flight for the same LDS, which is what these latency-bound passes lack.
+        constexpr int MAXB = (PTS + R - 1) / R;
+        cf u[MAXB][R];
+#pragma unroll
+        for (int b = 0; b < MAXB; b++) {
+            const int i = lane + b * tpf;
+            if (i < m) load(u[b], i);
+        }
+        if (!from_global && !to_global) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < MAXB; b++) {
+            const int i = lane + b * tpf;
+            if (i < m) finish(u[b], i);
         }
     }
 }
@@ -316,7 +341,8 @@ __device__ __forceinline__ void mixed_pass_prime(const MixedPass &ps, int n, int
     }
 }
 
-template <bool SWAP>
+// PTS = 0: two LDS images per frame (ping-pong); PTS > 0: one image, a lane holds up to PTS points across the barrier
+template <bool SWAP, int PTS>
 __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *out, const cf *__restrict__ twN,
                                                               const cf *twP, MixedDesc d, size_t batch,
                                                               float scale, int tpf, int tw_lds)
@@ -328,11 +354,13 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
     const int fpw = kMixedWG / tpf;
     const int fl = threadIdx.x / tpf;
     const int lane = threadIdx.x % tpf;
-    cf *bufA = reinterpret_cast<cf *>(smem_raw) + (size_t)fl * 2 * n;
-    cf *bufB = bufA + n;
+    constexpr bool INPLACE = PTS > 0;
+    constexpr int IMAGES = INPLACE ? 1 : 2;
+    cf *bufA = reinterpret_cast<cf *>(smem_raw) + (size_t)fl * IMAGES * n;
+    cf *bufB = INPLACE ? bufA : bufA + n;
     if (tw_lds) {
         // the pass twiddles sit behind the frame images: an LDS read per factor instead of a global one
-        cf *t = reinterpret_cast<cf *>(smem_raw) + (size_t)fpw * 2 * n;
+        cf *t = reinterpret_cast<cf *>(smem_raw) + (size_t)fpw * IMAGES * n;
         for (int e = threadIdx.x; e < tw_lds; e += kMixedWG) t[e] = twP[e];
         twP = t;
     }
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
         for (int s = 0; s < d.nfac; s++) {
             const MixedPass &ps = d.pass[s];
             const bool fg = (s == 0) && !d.stage, tg = (s == d.nfac - 1);
-#define AETH_PASS(RR) mixed_pass<RR, SWAP>(ps, n, lane, tpf, fg, tg, active, gin, gout, X, Y, twP, twN, scale)
+#define AETH_PASS(RR) mixed_pass<RR, SWAP, PTS>(ps, n, lane, tpf, fg, tg, active, gin, gout, X, Y, twP, twN, scale)
             switch (ps.R) {
             case 2: AETH_PASS(2); break;
             case 3: AETH_PASS(3); break;
@@ -403,29 +431,45 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
     int minr = d.nfac ? d.pass[0].R : 1;
     for (int i = 1; i < d.nfac; i++) if (d.pass[i].R < minr) minr = d.pass[i].R;
     const int need = d.nfac ? (d.n + minr - 1) / minr : d.n;
+    // one LDS image per frame (passes exchange in place) whenever every radix has a register form
+    bool all_small = d.nfac > 0;
+    for (int i = 0; i < d.nfac; i++) all_small = all_small && small_radix(d.pass[i].R);
+    const bool inplace = all_small && aeth::tuning_int("AETH_MIXED_INPLACE", 1) != 0;
+    const size_t frame_bytes = (size_t)((inplace && plan->len > 4096) ? 1 : 2) * plan->len * sizeof(cf);
     int tpf = aeth::tuning_int("AETH_MIXED_TPF", 0);
     if (tpf < 1 || tpf > kMixedWG || (tpf & (tpf - 1))) {
         int widest = 1;
         while (widest < need && widest < kMixedWG) widest <<= 1;
         tpf = widest < 8 ? widest : 8;
         // the LDS bound is the hard one (a frame of 4097..8192 samples takes one workgroup and up to 128 KiB)
-        while (tpf < kMixedWG && (size_t)(kMixedWG / tpf) * 2 * plan->len * sizeof(cf) > 36 * 1024) tpf <<= 1;
+        while (tpf < kMixedWG && (size_t)(kMixedWG / tpf) * frame_bytes > 36 * 1024) tpf <<= 1;
     }
+    while (inplace && tpf < kMixedWG && (size_t)32 * tpf < plan->len) tpf <<= 1;   // a lane holds n/tpf <= 32 points
+    // the one-image form (a lane keeps up to 32 points across a barrier: 142-190 VGPRs, two workgroups per
+    // CU, one more barrier per pass) pays off only where two images of the frame would leave room for a
+    // single workgroup per CU (measured: N = 6000 0.78 -> 1.39 TB/s, N <= 2048 up to 45 % slower)
+    const int pts = (inplace && plan->len > 4096) ? 32 : 0;
     const int fpw = kMixedWG / tpf;
     const size_t ngroups = (batch + fpw - 1) / fpw;
     size_t cap = (size_t)ctx->num_cus * 8;
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
-    size_t shmem = (size_t)fpw * 2 * plan->len * sizeof(cf);
+    size_t shmem = (size_t)fpw * (size_t)(pts ? 1 : 2) * plan->len * sizeof(cf);
     int tw_lds = 0;
     if (off > 0 && shmem + (size_t)off * sizeof(cf) <= 40 * 1024) {     // keeps >= 4 workgroups per CU
         tw_lds = off;
         shmem += (size_t)off * sizeof(cf);
     }
-    if (sign > 0)
-        hipLaunchKernelGGL((fft_mixed_kernel<true>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds);
-    else
-        hipLaunchKernelGGL((fft_mixed_kernel<false>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds);
+#define AETH_MIXED_LAUNCH(SW, IP)                                                                                        \
+    hipLaunchKernelGGL((fft_mixed_kernel<SW, IP>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in,       \
+                       (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds)
+#define AETH_MIXED_SIGN(IP) do { if (sign > 0) AETH_MIXED_LAUNCH(true, IP); else AETH_MIXED_LAUNCH(false, IP); } while (0)
+    switch (pts) {
+    case 32: AETH_MIXED_SIGN(32); break;
+    default: AETH_MIXED_SIGN(0); break;
+    }
+#undef AETH_MIXED_SIGN
+#undef AETH_MIXED_LAUNCH
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
