@@ -51,7 +51,7 @@ def lowpass_taps(ntaps=NTAPS, cutoff=0.25):
     return (t / t.sum()).astype(np.complex64)
 
 
-def cpu_baseline(budget_s=6.0):
+def cpu_baseline(budget_s=12.0):
     """Oracle (CPU restatement of the reference chain) on a bounded sample of the same workload."""
     from oracle import pyoracle as orc
     n = 1 << 22
