@@ -55,3 +55,43 @@ def test_fir_random_sweep(ctx, oracle):
         else:
             bound = 8 * 2.0 ** -23 * float(np.abs(np.concatenate([x, hist if use_hist else x[:0]])).max()) * float(np.abs(h).sum())
             assert np.abs(y - truth).max() <= bound, (fft_len, ntaps, n)
+
+
+def test_two_host_threads_two_contexts(oracle):
+    """SURVEY 8b threading: a context/plan is not thread-safe but distinct contexts run concurrently from
+    distinct host threads (each has its own stream, plans, staging and thread-local error text)."""
+    import threading
+    taps = oracle.synth_lowpass_taps(64, 0.25)
+    x = [rand_c64(900 + t, (1 << 18) + 77 * t) for t in range(2)]
+    want = []
+    c0 = ap.Context(0)
+    for t in range(2):                                       # single-threaded reference run
+        f = ap.Fir(c0, taps, 2048); h = ap.HipFft(c0, 1024)
+        y = f.filter(c0.vec(x[t])).to_host()
+        m = (x[t].size // 1024) * 1024
+        s = c0.vec(x[t][:m]); h.ifwd(s, ap.Scale.SN)
+        want.append((y, s.to_host()))
+    got, errs = [None, None], []
+
+    def work(t):
+        try:
+            c = ap.Context(0)
+            f = ap.Fir(c, taps, 2048); h = ap.HipFft(c, 1024)
+            m = (x[t].size // 1024) * 1024
+            for _ in range(20):
+                y = f.filter(c.vec(x[t])).to_host()
+                s = c.vec(x[t][:m]); h.ifwd(s, ap.Scale.SN)
+                sp = s.to_host()
+                with pytest.raises(ap.LengthMismatch):       # error text is per thread
+                    c.vec(x[t][:5]).vec_add(c.vec(x[t][:4]))
+            got[t] = (y, sp)
+            c.close()
+        except Exception as e:                               # noqa: BLE001 - reported below
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for t in range(2):
+        assert bits_equal(got[t][0], want[t][0]) and bits_equal(got[t][1], want[t][1])
+    c0.close()
