@@ -6,6 +6,10 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 #[repr(C)] pub struct aeth_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct aeth_fft { _p: [u8; 0] }
 #[repr(C)] pub struct aeth_fir { _p: [u8; 0] }
+#[repr(C)] pub struct aeth_event { _p: [u8; 0] }
+/// aeth_pipe_stats: what the double-buffered host-stream pipeline reports
+#[repr(C)] #[derive(Default, Clone, Copy)]
+pub struct aeth_pipe_stats { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64 }
 
 pub const AETH_OK: c_int = 0;
 pub const AETH_E_LEN: c_int = -1;
@@ -22,7 +26,18 @@ pub const AETH_SIGN_REF_BWD: c_int = -1;
 // cf32 = Complex<f32> is repr(C) {re, im} (src/lib.rs:8-12) == aeth_cf32
 extern "C" {
     pub fn aeth_last_error() -> *const c_char;
+    pub fn aeth_version() -> c_int;
+    pub fn aeth_device_count(count: *mut c_int) -> c_int;
     pub fn aeth_ctx_create(device: c_int, out: *mut *mut aeth_ctx) -> c_int;
+    pub fn aeth_ctx_create_on_stream(device: c_int, hip_stream: *mut c_void, out: *mut *mut aeth_ctx) -> c_int;
+    pub fn aeth_ctx_stream(ctx: *mut aeth_ctx) -> *mut c_void;
+    pub fn aeth_ctx_device(ctx: *const aeth_ctx) -> c_int;
+    pub fn aeth_copy_dev(ctx: *mut aeth_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn aeth_event_create(ctx: *mut aeth_ctx, out: *mut *mut aeth_event) -> c_int;
+    pub fn aeth_event_destroy(ev: *mut aeth_event) -> c_int;
+    pub fn aeth_event_record(ev: *mut aeth_event) -> c_int;
+    pub fn aeth_event_sync(ev: *mut aeth_event) -> c_int;
+    pub fn aeth_event_elapsed_ms(start: *mut aeth_event, stop: *mut aeth_event, ms: *mut c_float) -> c_int;
     pub fn aeth_ctx_destroy(ctx: *mut aeth_ctx) -> c_int;
     pub fn aeth_ctx_sync(ctx: *mut aeth_ctx) -> c_int;
     pub fn aeth_dev_alloc(ctx: *mut aeth_ctx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
@@ -39,10 +54,26 @@ extern "C" {
     pub fn aeth_vec_mirror(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
     pub fn aeth_vec_clone(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
     pub fn aeth_vec_zero(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
+    pub fn aeth_vec_mirror_frames(ctx: *mut aeth_ctx, s: *mut cf32, frame_len: usize, batch: usize) -> c_int;
+    // host-slice flavours: the literal `impl VecOps for [cf32]` semantics, one H2D + D2H per call
+    pub fn aeth_host_vec_scale(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, scale: c_float) -> c_int;
+    pub fn aeth_host_vec_mul(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_host_vec_div(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_host_vec_conj(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
+    pub fn aeth_host_vec_add(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_host_vec_sub(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_host_vec_mirror(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
+    pub fn aeth_host_vec_clone(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_host_vec_zero(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
+    pub fn aeth_scale_factor(kind: c_int, n: usize, x: c_float) -> c_float;
+    pub fn aeth_scale_apply(ctx: *mut aeth_ctx, kind: c_int, x: c_float, data: *mut cf32, n: usize) -> c_int;
 
     pub fn aeth_fft_create(ctx: *mut aeth_ctx, len: usize, max_batch: usize, out: *mut *mut aeth_fft) -> c_int;
     pub fn aeth_fft_destroy(plan: *mut aeth_fft) -> c_int;
     pub fn aeth_fft_len(plan: *const aeth_fft) -> usize;
+    pub fn aeth_fft_algorithm(plan: *const aeth_fft) -> *const c_char;
+    pub fn aeth_fft_exec_tmp(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, batch: usize, sign: c_int,
+                             scale_kind: c_int, x: c_float, view: *mut *const cf32) -> c_int;
     pub fn aeth_fft_exec(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, batch: usize,
                          sign: c_int, scale_kind: c_int, x: c_float) -> c_int;
     pub fn aeth_fft_exec_host(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, n_out: usize,
@@ -57,6 +88,23 @@ extern "C" {
     pub fn aeth_fir_destroy(fir: *mut aeth_fir) -> c_int;
     pub fn aeth_fir_exec(fir: *mut aeth_fir, hist: *const cf32, inp: *const cf32, n: usize, out: *mut cf32) -> c_int;
     pub fn aeth_fir_exec_host(fir: *mut aeth_fir, hist: *const cf32, inp: *const cf32, n: usize, out: *mut cf32) -> c_int;
+    pub fn aeth_fir_ntaps(fir: *const aeth_fir) -> usize;
+    pub fn aeth_fir_fft_len(fir: *const aeth_fir) -> usize;
+    pub fn aeth_fir_hop(fir: *const aeth_fir) -> usize;
+    pub fn aeth_fir_stream_host(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,
+                                stats: *mut aeth_pipe_stats) -> c_int;
+    pub fn aeth_fir_stream_file(fir: *mut aeth_fir, in_path: *const c_char, out_path: *const c_char, chunk: usize,
+                                stats: *mut aeth_pipe_stats) -> c_int;
+    pub fn aeth_file_count_structs(path: *const c_char, elem_size: usize, count: *mut usize) -> c_int;
+    pub fn aeth_file_read(path: *const c_char, first_elem: usize, dst: *mut c_void, n: usize, elem_size: usize) -> c_int;
+    pub fn aeth_file_write(path: *const c_char, src: *const c_void, n: usize, elem_size: usize, append: c_int) -> c_int;
+
+    pub fn aeth_interpolate(ctx: *mut aeth_ctx, src: *const cf32, n_src: usize, dst: *mut cf32, cap: usize,
+                            n_between: usize, compat_im: c_int, n_written: *mut usize) -> c_int;
+    pub fn aeth_interpolate_frames(ctx: *mut aeth_ctx, src: *const cf32, frame_len: usize, batch: usize, dst: *mut cf32,
+                                   cap: usize, n_between: usize, compat_im: c_int, n_written: *mut usize) -> c_int;
+    pub fn aeth_downsample(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void, n_dst: usize,
+                           elem_size: usize) -> c_int;
 
     pub fn aeth_host_interpolate(ctx: *mut aeth_ctx, src: *const cf32, n_src: usize, dst: *mut cf32, cap: usize,
                                  n_between: usize, compat_im: c_int, n_written: *mut usize) -> c_int;

@@ -27,6 +27,10 @@ fn scale_args(s: Scale) -> (i32, f32) {
 
 /// One device + one HIP stream.  `Send` (may move between pipeline threads like a
 /// pooled `Cfft`, src/pool.rs:69-71), not `Sync` (every method takes `&mut self`).
+///
+/// Device objects (`DeviceVec`, plans) borrow the context SHARED, so several can live at once; the
+/// context itself is `!Sync` (raw pointer), which keeps all of them on one thread at a time as the
+/// C side requires.
 pub struct Context { h: *mut aeth_ctx }
 unsafe impl Send for Context {}
 impl Context {
@@ -35,7 +39,7 @@ impl Context {
         check(unsafe { aeth_ctx_create(device, &mut h) });
         Context { h }
     }
-    pub fn sync(&mut self) { check(unsafe { aeth_ctx_sync(self.h) }) }
+    pub fn sync(&self) { check(unsafe { aeth_ctx_sync(self.h) }) }
 }
 impl Drop for Context { fn drop(&mut self) { unsafe { aeth_ctx_destroy(self.h); } } }
 
@@ -44,14 +48,14 @@ pub struct HipFft { h: *mut aeth_fft }
 unsafe impl Send for HipFft {}
 impl HipFft {
     /// `Cfft::with_len` (src/fft.rs:147)
-    pub fn with_len(ctx: &mut Context, len: usize) -> HipFft {
+    pub fn with_len(ctx: &Context, len: usize) -> HipFft {
         let mut h = ptr::null_mut();
         check(unsafe { aeth_fft_create(ctx.h, len, 1, &mut h) });
         HipFft { h }
     }
-    fn host(&mut self, input: &[cf32], output: *mut cf32, n_out: usize, sign: i32, s: Scale) {
+    fn host(&mut self, input: *const cf32, n_in: usize, output: *mut cf32, n_out: usize, sign: i32, s: Scale) {
         let (k, x) = scale_args(s);
-        check(unsafe { aeth_fft_exec_host(self.h, input.as_ptr(), input.len(), output, n_out, sign, k, x) });
+        check(unsafe { aeth_fft_exec_host(self.h, input, n_in, output, n_out, sign, k, x) });
     }
     fn tmp(&mut self, input: &[cf32], sign: i32, s: Scale) -> &[cf32] {
         let (k, x) = scale_args(s);
@@ -65,18 +69,18 @@ impl Drop for HipFft { fn drop(&mut self) { unsafe { aeth_fft_destroy(self.h); }
 
 impl Fft for HipFft {
     fn fwd(&mut self, input: &[cf32], output: &mut [cf32], s: Scale) {
-        self.host(input, output.as_mut_ptr(), output.len(), AETH_SIGN_REF_FWD, s)
+        self.host(input.as_ptr(), input.len(), output.as_mut_ptr(), output.len(), AETH_SIGN_REF_FWD, s)
     }
     fn bwd(&mut self, input: &[cf32], output: &mut [cf32], s: Scale) {
-        self.host(input, output.as_mut_ptr(), output.len(), AETH_SIGN_REF_BWD, s)
+        self.host(input.as_ptr(), input.len(), output.as_mut_ptr(), output.len(), AETH_SIGN_REF_BWD, s)
     }
     fn ifwd(&mut self, input: &mut [cf32], s: Scale) {
         let (p, n) = (input.as_mut_ptr(), input.len());
-        self.host(unsafe { std::slice::from_raw_parts(p, n) }, p, n, AETH_SIGN_REF_FWD, s)
+        self.host(p as *const cf32, n, p, n, AETH_SIGN_REF_FWD, s)     // in == out: in place on the C side
     }
     fn ibwd(&mut self, input: &mut [cf32], s: Scale) {
         let (p, n) = (input.as_mut_ptr(), input.len());
-        self.host(unsafe { std::slice::from_raw_parts(p, n) }, p, n, AETH_SIGN_REF_BWD, s)
+        self.host(p as *const cf32, n, p, n, AETH_SIGN_REF_BWD, s)
     }
     fn tfwd(&mut self, input: &[cf32], s: Scale) -> &[cf32] { self.tmp(input, AETH_SIGN_REF_FWD, s) }
     fn tbwd(&mut self, input: &[cf32], s: Scale) -> &[cf32] { self.tmp(input, AETH_SIGN_REF_BWD, s) }
@@ -84,9 +88,9 @@ impl Fft for HipFft {
 }
 
 /// Device-resident `[cf32]` with the `VecOps` method set (src/vecops.rs:39-89).
-pub struct DeviceVec<'c> { ctx: &'c mut Context, p: *mut cf32, n: usize }
+pub struct DeviceVec<'c> { ctx: &'c Context, p: *mut cf32, n: usize }
 impl<'c> DeviceVec<'c> {
-    pub fn from_slice(ctx: &'c mut Context, host: &[cf32]) -> DeviceVec<'c> {
+    pub fn from_slice(ctx: &'c Context, host: &[cf32]) -> DeviceVec<'c> {
         let mut p: *mut c_void = ptr::null_mut();
         check(unsafe { aeth_dev_alloc(ctx.h, host.len() * 8, &mut p) });
         check(unsafe { aeth_upload(ctx.h, p, host.as_ptr() as *const c_void, host.len() * 8) });
@@ -129,7 +133,7 @@ impl<'c> Drop for DeviceVec<'c> { fn drop(&mut self) { unsafe { aeth_dev_free(se
 pub mod sampling {
     use super::*;
     /// `sampling::interpolate` (src/sampling.rs:7-24): APPENDS to `dst`.
-    pub fn interpolate(ctx: &mut Context, src: &[cf32], dst: &mut Vec<cf32>, n_between: usize) {
+    pub fn interpolate(ctx: &Context, src: &[cf32], dst: &mut Vec<cf32>, n_between: usize) {
         assert!(!src.is_empty());                              // the reference unwrap()s src.last()
         let add = src.len() + (src.len() - 1) * n_between;
         dst.reserve(add);
@@ -139,8 +143,51 @@ pub mod sampling {
         unsafe { dst.set_len(dst.len() + written) };
     }
     /// `sampling::downsample<T: Copy>` (src/sampling.rs:28-42)
-    pub fn downsample<T: Copy>(ctx: &mut Context, src: &[T], dst: &mut [T]) {
+    pub fn downsample<T: Copy>(ctx: &Context, src: &[T], dst: &mut [T]) {
         check(unsafe { aeth_host_downsample(ctx.h, src.as_ptr() as *const c_void, src.len(),
                                             dst.as_mut_ptr() as *mut c_void, dst.len(), std::mem::size_of::<T>()) });
+    }
+}
+
+/// Overlap-save FIR behind `fir::Fir`'s constructor shape (src/fir.rs:3-22 stores taps and a scratch but has
+/// no filter method; this one filters).
+pub struct Fir { h: *mut aeth_fir }
+unsafe impl Send for Fir {}
+impl Fir {
+    pub fn new(ctx: &Context, taps: &[cf32], fft_len: usize) -> Fir {
+        let mut h = ptr::null_mut();
+        check(unsafe { aeth_fir_create(ctx.h, taps.as_ptr(), taps.len(), fft_len, &mut h) });
+        Fir { h }
+    }
+    /// device-resident stream: y[n] = sum_k taps[k] x[n-k], zero initial state
+    pub fn filter(&mut self, x: &DeviceVec, y: &mut DeviceVec) {
+        assert_eq!(x.n, y.n, "Vectors must have same length");
+        check(unsafe { aeth_fir_exec(self.h, ptr::null(), x.p, x.n, y.p) });
+    }
+    /// host-resident stream through the double-buffered H2D | kernel | D2H pipeline (src/pipeline.rs counterpart)
+    pub fn filter_stream(&mut self, x: &[cf32], y: &mut [cf32]) -> aeth_pipe_stats {
+        assert_eq!(x.len(), y.len(), "Vectors must have same length");
+        let mut st = aeth_pipe_stats::default();
+        check(unsafe { aeth_fir_stream_host(self.h, x.as_ptr(), x.len(), y.as_mut_ptr(), 0, &mut st) });
+        st
+    }
+}
+impl Drop for Fir { fn drop(&mut self) { unsafe { aeth_fir_destroy(self.h); } } }
+
+/// `modulation::Modulation` for the generic BPSK/QPSK tables (src/modulation.rs:5-149) on device buffers,
+/// and `noise::Awgn::apply` (src/noise.rs:53-59).
+pub mod modem {
+    use super::*;
+    /// `m.modulate(&bits)`: one u8 per bit in, `bits.len() / bits_per_symbol` symbols out
+    pub fn modulate(ctx: &Context, bits_dev: *const u8, nbits: usize, bits_per_symbol: i32, out: &mut DeviceVec) {
+        check(unsafe { aeth_modulate(ctx.h, bits_dev, nbits, bits_per_symbol, ptr::null(), out.p, out.n) });
+    }
+    /// `m.demod_naive(..)`; `compat` reproduces the reference's `idx & 1u8 << 1` output (src/modulation.rs:54)
+    pub fn demod_naive(ctx: &Context, sym: &DeviceVec, bits_per_symbol: i32, bits_dev: *mut u8, nbits: usize, compat: bool) {
+        check(unsafe { aeth_demod_naive(ctx.h, sym.p, sym.n, bits_per_symbol, ptr::null(), bits_dev, nbits, compat as i32) });
+    }
+    /// `noise::new(power, seed).apply(&mut signal)` -- the double scaling of the reference is kept
+    pub fn awgn_apply(ctx: &Context, signal: &mut DeviceVec, power: f32, seed: u64, offset: u64) {
+        check(unsafe { aeth_awgn_apply(ctx.h, signal.p, signal.n, power, seed, offset) });
     }
 }
