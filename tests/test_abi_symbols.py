@@ -43,6 +43,13 @@ def test_ctypes_table_matches_header():
     assert lib.aeth_version() >= 0x000100
 
 
+def test_rust_binding_declares_the_whole_header():
+    """rust/src/ffi.rs (the binding a maintainer adds; uncompiled here) stays one to one with the header."""
+    ffi = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    declared = set(re.findall(r"pub fn (aeth_[a-z0-9_]+)\s*\(", ffi))
+    assert sorted(declared) == header_symbols()
+
+
 def test_product_never_links_the_oracle():
     """The product path must not import / link anything under oracle/."""
     from aether_primitives_amd import _lib
