@@ -302,12 +302,21 @@ int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batc
     if (sign > 0) hipLaunchKernelGGL((blu_pre<true>), dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
     else          hipLaunchKernelGGL((blu_pre<false>), dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
     AETH_HIP(hipGetLastError());
-    rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, -1, 1.0f);
-    if (rc) return rc;
-    hipLaunchKernelGGL(blu_mul, dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, a, (const cf *)plan->blu_filt, M, batch);
-    AETH_HIP(hipGetLastError());
-    rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, +1, 1.0f);
-    if (rc) return rc;
+    if (plan->blu_sub->algo == FFT_ALGO_POW2 && M <= 4096) {
+        // circular convolution in ONE launch of the fused transform * filter * inverse kernel.  It runs +j then
+        // -j where the three-launch form runs -j then +j; the filter is symmetric (b[n] = b[M-n]), so its
+        // spectrum is the same under both signs and the convolution comes out identical in exact arithmetic.
+        rc = aeth_fft_mul_ifft(plan->blu_sub, (aeth_cf32 *)plan->work_dev, M * batch, batch, (const aeth_cf32 *)plan->blu_filt,
+                               M, AETH_SCALE_NONE, 0.f, AETH_SCALE_NONE, 0.f);
+        if (rc) return rc;
+    } else {
+        rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, -1, 1.0f);
+        if (rc) return rc;
+        hipLaunchKernelGGL(blu_mul, dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, a, (const cf *)plan->blu_filt, M, batch);
+        AETH_HIP(hipGetLastError());
+        rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, +1, 1.0f);
+        if (rc) return rc;
+    }
     if (sign > 0) hipLaunchKernelGGL((blu_post<true>), dim3(grid_for(ctx, N * batch)), b, 0, ctx->stream, (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
     else          hipLaunchKernelGGL((blu_post<false>), dim3(grid_for(ctx, N * batch)), b, 0, ctx->stream, (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
     AETH_HIP(hipGetLastError());
