@@ -78,7 +78,11 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel32(const float2 *__r
         e = slot[q];
         fi = (float)i;
         const float2 v1 = make_float2(e.x + fi * e.z, e.y + fi * e.w);
-        if (wide_store) *reinterpret_cast<float4 *>(dst + o) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        if (wide_store) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 pack = {v0.x, v0.y, v1.x, v1.y};
+            __builtin_nontemporal_store(pack, reinterpret_cast<f4 *>(dst + o));   // written once, never read back here
+        }
         else { dst[o] = v0; dst[o + 1] = v1; }
     }
 }
