@@ -49,7 +49,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
         cf *dst = out + frame * C::N + tid;
         cf w[C::P];
 #pragma unroll
-        for (int m = 0; m < C::P; m++) w[m] = active ? src[m * C::T] : mk(0.f, 0.f);
+        for (int m = 0; m < C::P; m++) w[m] = active ? __builtin_nontemporal_load(src + m * C::T) : mk(0.f, 0.f);
         // an odd number of exchanges per transform flips the image parity every frame
         if (fft_next_par<C>(0) == 0 || !par) fft_in_regs<C, S, 0>(w, tw, lds, tid);
         else fft_in_regs<C, S, 1>(w, tw, lds, tid);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
         if (active) {
             const cf ss = mk(scale, scale);
 #pragma unroll
-            for (int m = 0; m < C::P; m++) dst[m * C::T] = cscale_k(w[m], ss);
+            for (int m = 0; m < C::P; m++) __builtin_nontemporal_store(cscale_k(w[m], ss), dst + m * C::T);
         }
     }
 }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf
                                                     active ? C::N * 8 : 0, 0x00020000);
 #pragma unroll
         for (int m = 0; m < C::P; m++)
-            x[m] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 0));
+            x[m] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 2));
     };
     cf nx[C::P];
     fetch(nx, blockIdx.x);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf
         auto ws = __builtin_amdgcn_make_buffer_rsrc(out + g * C::N, 0, C::N * 8, 0x00020000);
 #pragma unroll
         for (int m = 0; m < C::P; m++)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, 2);   // aux 2: non-temporal, frames are streamed once
     }
 }
 
