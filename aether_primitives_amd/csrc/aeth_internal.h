@@ -59,6 +59,24 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f)
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+// Streamed data (touched exactly once by a kernel) is accessed with the non-temporal hint: no write-allocate,
+// no retention in L2.  Measured on MI355X: element-wise kernels 5.9 -> 6.5 TB/s, batched FFT 5.4 -> 5.8-6.1,
+// interpolate 5.5 -> 6.2, the fused FIR kernel -3 % launch time.
+template <typename V> __device__ __forceinline__ V nt_load(const V *p)
+{
+    static_assert(sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 16, "4-, 8- or 16-byte accesses");
+    typedef unsigned VT __attribute__((ext_vector_type(sizeof(V) / 4)));
+    if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p)));
+    else return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const VT *>(p)));
+}
+template <typename V> __device__ __forceinline__ void nt_store(V *p, V v)
+{
+    static_assert(sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 16, "4-, 8- or 16-byte accesses");
+    typedef unsigned VT __attribute__((ext_vector_type(sizeof(V) / 4)));
+    if constexpr (sizeof(V) == 4) __builtin_nontemporal_store(__builtin_bit_cast(unsigned, v), reinterpret_cast<unsigned *>(p));
+    else __builtin_nontemporal_store(__builtin_bit_cast(VT, v), reinterpret_cast<VT *>(p));
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;

@@ -51,14 +51,14 @@ __global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restr
         constexpr int SPL = 4 / BPS;                     // symbols per lane: 4 bytes of bits
         const size_t s0 = i * SPL;
         if (s0 >= nsym) return;
-        const uchar4 b = reinterpret_cast<const uchar4 *>(bits)[i];
+        const uchar4 b = aeth::nt_load(reinterpret_cast<const uchar4 *>(bits) + i);
         if constexpr (BPS == 2) {
             const float2 a = pick(t, qpsk_index(b.x, b.y)), c = pick(t, qpsk_index(b.z, b.w));
-            reinterpret_cast<float4 *>(out)[i] = make_float4(a.x, a.y, c.x, c.y);
+            aeth::nt_store(reinterpret_cast<float4 *>(out) + i, make_float4(a.x, a.y, c.x, c.y));
         } else {
             const float2 a = pick(t, b.x & 1u), c = pick(t, b.y & 1u), d = pick(t, b.z & 1u), e = pick(t, b.w & 1u);   // modulation.rs:9-12
-            reinterpret_cast<float4 *>(out)[2 * i] = make_float4(a.x, a.y, c.x, c.y);
-            reinterpret_cast<float4 *>(out)[2 * i + 1] = make_float4(d.x, d.y, e.x, e.y);
+            aeth::nt_store(reinterpret_cast<float4 *>(out) + 2 * i, make_float4(a.x, a.y, c.x, c.y));
+            aeth::nt_store(reinterpret_cast<float4 *>(out) + 2 * i + 1, make_float4(d.x, d.y, e.x, e.y));
         }
     } else {
         if (i >= nsym) return;
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(kBlock) void demod_kernel(const float2 *__restrict_
         constexpr int SPL = 4 / BPS;
         if (i * SPL >= nsym) return;
         if constexpr (BPS == 2) {
-            const float4 v = reinterpret_cast<const float4 *>(sym)[i];
+            const float4 v = aeth::nt_load(reinterpret_cast<const float4 *>(sym) + i);
             const unsigned a = nearest(make_float2(v.x, v.y), t, NC), c = nearest(make_float2(v.z, v.w), t, NC);
-            reinterpret_cast<uchar4 *>(bits)[i] = make_uchar4((uint8_t)(a & 1u), hi(a), (uint8_t)(c & 1u), hi(c));
+            aeth::nt_store(reinterpret_cast<uchar4 *>(bits) + i, make_uchar4((uint8_t)(a & 1u), hi(a), (uint8_t)(c & 1u), hi(c)));
         } else {
-            const float4 v = reinterpret_cast<const float4 *>(sym)[2 * i], w = reinterpret_cast<const float4 *>(sym)[2 * i + 1];
+            const float4 v = aeth::nt_load(reinterpret_cast<const float4 *>(sym) + 2 * i), w = aeth::nt_load(reinterpret_cast<const float4 *>(sym) + 2 * i + 1);
             reinterpret_cast<uchar4 *>(bits)[i] = make_uchar4((uint8_t)(nearest(make_float2(v.x, v.y), t, NC) & 1u),
                                                               (uint8_t)(nearest(make_float2(v.z, v.w), t, NC) & 1u),
                                                               (uint8_t)(nearest(make_float2(w.x, w.y), t, NC) & 1u),

@@ -37,12 +37,12 @@ __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__
         if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
     }
     if (wide && i0 + 1 < n) {
-        float4 v = *reinterpret_cast<float4 *>(x + i0);
+        float4 v = aeth::nt_load(reinterpret_cast<float4 *>(x + i0));
         v.x = v.x + (n0r * scale) * scale;          // noise.rs:41 then :58
         v.y = v.y + (n0i * scale) * scale;
         v.z = v.z + (n1r * scale) * scale;
         v.w = v.w + (n1i * scale) * scale;
-        *reinterpret_cast<float4 *>(x + i0) = v;
+        aeth::nt_store(reinterpret_cast<float4 *>(x + i0), v);
     } else {
         float2 a = x[i0];
         a.x = a.x + (n0r * scale) * scale;

@@ -115,7 +115,10 @@ __global__ __launch_bounds__(kBlock) void downsample_kernel(const T *__restrict_
                                                             size_t n_dst, size_t dec)
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n_dst) dst[i] = src[i * dec];         // *c = src[i * dec]       (sampling.rs:39-41)
+    if (i < n_dst) {                               // *c = src[i * dec]       (sampling.rs:39-41)
+        if constexpr (sizeof(T) >= 4) aeth::nt_store(dst + i, src[i * dec]);
+        else dst[i] = src[i * dec];
+    }
 }
 
 // one item per lane, the grid covers everything (see aeth_vecops.hip on why no capped loop)

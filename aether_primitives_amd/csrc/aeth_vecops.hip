@@ -57,21 +57,14 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(V *__restrict__ self, const 
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    // every element is touched exactly once: non-temporal accesses (no write-allocate, no L2 retention)
-    typedef float VT __attribute__((ext_vector_type(sizeof(V) / 4)));
+    // every element is touched exactly once: non-temporal accesses (aeth_internal.h)
     V a, b;
-    if constexpr (reads_self<OP>()) a = __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const VT *>(self + i)));
-    if constexpr (reads_other<OP>()) b = __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const VT *>(other + i)));
-    if constexpr (OP == OP_CONJ) {
-        // conj leaves the real parts as loaded; without this hipcc narrows the access to the imaginary
-        // dwords only (4-byte loads and stores at stride 8), which costs 10 % of the bandwidth
-        if constexpr (sizeof(V) == 16) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
-        else asm volatile("" : "+v"(a.x), "+v"(a.y));
-    }
+    if constexpr (reads_self<OP>()) a = aeth::nt_load(self + i);
+    if constexpr (reads_other<OP>()) b = aeth::nt_load(other + i);
     V r;
     if constexpr (sizeof(V) == 16) r = apply4<OP>(a, b, s);
     else r = apply2<OP>(a, b, s);
-    __builtin_nontemporal_store(__builtin_bit_cast(VT, r), reinterpret_cast<VT *>(self + i));
+    aeth::nt_store(self + i, r);
 }
 
 inline unsigned grid_for(const aeth_ctx *, size_t items)
@@ -121,9 +114,9 @@ __global__ __launch_bounds__(kBlock) void mirror_kernel(V *__restrict__ x, size_
     if (i >= batch * mid_v) return;
     size_t f = i / mid_v, j = i - f * mid_v;
     V *p = x + f * frame_stride_v + j;
-    V lo = p[0], hi = p[mid_v];
-    p[0] = hi;
-    p[mid_v] = lo;
+    V lo = aeth::nt_load(p), hi = aeth::nt_load(p + mid_v);
+    aeth::nt_store(p, hi);
+    aeth::nt_store(p + mid_v, lo);
 }
 
 int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch)
