@@ -28,7 +28,8 @@ using namespace aeth::fftk;
 namespace {
 
 // =============================== stockham_pow2 ================================
-template <class C, int S>
+// NT: frames are streamed with the non-temporal hint (batches beyond the cache; aeth_internal.h)
+template <class C, int S, bool NT>
 __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
                                                           const cf *__restrict__ twL, size_t batch, float scale)
 {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
         cf *dst = out + frame * C::N + tid;
         cf w[C::P];
 #pragma unroll
-        for (int m = 0; m < C::P; m++) w[m] = active ? __builtin_nontemporal_load(src + m * C::T) : mk(0.f, 0.f);
+        for (int m = 0; m < C::P; m++) w[m] = active ? aeth::nt_load<NT>(src + m * C::T) : mk(0.f, 0.f);
         // an odd number of exchanges per transform flips the image parity every frame
         if (fft_next_par<C>(0) == 0 || !par) fft_in_regs<C, S, 0>(w, tw, lds, tid);
         else fft_in_regs<C, S, 1>(w, tw, lds, tid);
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
         if (active) {
             const cf ss = mk(scale, scale);
 #pragma unroll
-            for (int m = 0; m < C::P; m++) __builtin_nontemporal_store(cscale_k(w[m], ss), dst + m * C::T);
+            for (int m = 0; m < C::P; m++) aeth::nt_store<NT>(dst + m * C::T, cscale_k(w[m], ss));
         }
     }
 }
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
 // while this one is transformed, table loads drained once before the loop.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <class C, int S>
+template <class C, int S, bool NT>
 __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf *out, const cf *__restrict__ twL,
                                                                  size_t batch, float scale)
 {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf
                                                     active ? C::N * 8 : 0, 0x00020000);
 #pragma unroll
         for (int m = 0; m < C::P; m++)
-            x[m] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, 2));
+            x[m] = __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
     };
     cf nx[C::P];
     fetch(nx, blockIdx.x);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf
         auto ws = __builtin_amdgcn_make_buffer_rsrc(out + g * C::N, 0, C::N * 8, 0x00020000);
 #pragma unroll
         for (int m = 0; m < C::P; m++)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, 2);   // aux 2: non-temporal, frames are streamed once
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, NT ? 2 : 0);   // aux 2 = non-temporal
     }
 }
 
@@ -110,6 +111,7 @@ template <class C>
 int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
     const aeth_ctx *ctx = plan->ctx;
+    const bool nt = aeth::streams_past_cache(2 * batch * (size_t)C::N * sizeof(float2));
     size_t ngroups = (batch + C::F - 1) / C::F;
     size_t cap = (size_t)ctx->num_cus * 8;
     int grid = (int)(ngroups < cap ? ngroups : cap);
@@ -120,16 +122,18 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
         int grid2 = (int)(batch < cap2 ? batch : cap2);
         if (grid2 < 1) grid2 = 1;
         if (!aeth::tuning_int("AETH_FFT_NOSTREAM", 0)) {
-            if (sign > 0) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, +1>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
-            else          hipLaunchKernelGGL((fft_pow2_stream_kernel<C, -1>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
+#define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+            if (sign > 0) { if (nt) AETH_FFT_STREAM(+1, true); else AETH_FFT_STREAM(+1, false); }
+            else          { if (nt) AETH_FFT_STREAM(-1, true); else AETH_FFT_STREAM(-1, false); }
+#undef AETH_FFT_STREAM
             AETH_HIP(hipGetLastError());
             return AETH_OK;
         }
     }
-    if (sign > 0)
-        hipLaunchKernelGGL((fft_pow2_kernel<C, +1>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
-    else
-        hipLaunchKernelGGL((fft_pow2_kernel<C, -1>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale);
+#define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+    if (sign > 0) { if (nt) AETH_FFT_PLAIN(+1, true); else AETH_FFT_PLAIN(+1, false); }
+    else          { if (nt) AETH_FFT_PLAIN(-1, true); else AETH_FFT_PLAIN(-1, false); }
+#undef AETH_FFT_PLAIN
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

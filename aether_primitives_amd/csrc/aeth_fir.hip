@@ -53,16 +53,16 @@ struct FmiArgs {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// Stream accesses carry the non-temporal hint (aux bit 1): a window is read once and an output block is written
-// once, so neither should displace the tables in L2 or take the write-allocate path (A/B in one process:
-// stores alone -3 %, loads alone +3 %, both -5 % of the launch time).
-constexpr int kAuxNT = 2;
+// Stream accesses carry the non-temporal hint (aux bit 1) when the launch moves more than the cache holds: a
+// window is read once and an output block written once, so neither should displace the tables in L2 or take the
+// write-allocate path (A/B in one process on 256 MiB: stores alone -3 %, loads alone +3 %, both -5 % of the launch
+// time).  NT is a kernel template parameter: short chains over cache-sized operands (C4) keep plain accesses.
 
 __device__ __forceinline__ cf as_cf(u32x2 v) { return __builtin_bit_cast(cf, v); }
 __device__ __forceinline__ u32x2 as_u32x2(cf v) { return __builtin_bit_cast(u32x2, v); }
 
 // one block's input window -> registers (slot m = window element tid + m*T)
-template <class C>
+template <class C, bool NT>
 __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
 {
     const long long win0 = blk * a.hop - a.ov;              // first input sample of the window
@@ -79,7 +79,7 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
             auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
             for (int m = 0; m < C::P; m++)
-                x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, kAuxNT));
+                x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
             // (the window's oldest ov-nhist samples are zeroed when the window is consumed: doing it
             // here would put a wait for the load right behind its issue)
             return;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
 // the caller): a block past the end gets a zero-length descriptor, so the loads still
 // issue -- and return zeros without touching memory.  No divergent path means hipcc can
 // COUNT the loads in flight (vmcnt(N)) instead of falling back to vmcnt(0).
-template <class C>
+template <class C, bool NT>
 __device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
 {
     const bool active = blk < a.nblocks;
@@ -111,10 +111,10 @@ __device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a,
     auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
     for (int m = 0; m < C::P; m++)
-        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, kAuxNT));
+        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
 }
 
-template <class C, bool SCALED>
+template <class C, bool SCALED, bool NT>
 __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
 {
     if (blk >= a.nblocks) return;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
             const int e = tid + m * C::T;
             const int off = (e >= a.ov) ? e * 8 : 0x7ffffff0;
             cf v = SCALED ? cscale_k(w[m], ss) : w[m];
-            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, kAuxNT);
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 2 : 0);
         }
     } else {
 #pragma unroll
@@ -144,7 +144,7 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
 }
 
 // SCALED = false: both Scale factors are 1 (FIR: 1/N is folded into H)
-template <class C, bool SCALED, int MINW>
+template <class C, bool SCALED, int MINW, bool NT>
 __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
 {
     __shared__ cf lds_all[C::LDS_TOTAL];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
     // software pipeline: the next block's window is in flight while this one is transformed.
     // The first window goes out before the (L2-resident) tables so the HBM fetch starts at once.
     cf nx[C::P];
-    load_window<C>(nx, a, (long long)blockIdx.x * C::F + fl, tid);
+    load_window<C, NT>(nx, a, (long long)blockIdx.x * C::F + fl, tid);
 
     cf tw[C::TW];
     if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
@@ -183,9 +183,9 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         const long long gn = g + gridDim.x;
         if constexpr (C::F == 1) {
             // gn >= gridDim.x >= 1, so the window never starts before the stream: descriptor path
-            load_window_srd<C>(nx, a, gn, tid);
+            load_window_srd<C, NT>(nx, a, gn, tid);
         } else {
-            if (gn < ngroups) load_window<C>(nx, a, gn * C::F + fl, tid);
+            if (gn < ngroups) load_window<C, NT>(nx, a, gn * C::F + fl, tid);
         }
 
         fft_in_regs<C, +1, 0>(w, tw, lds, tid);             // vec_rfft: the reference's fwd (+j exponent)
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
 #pragma unroll
         for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);             // vec_mul (vecops.rs:99-112)
         fft_in_regs<C, -1, fft_next_par<C>(0)>(w, tw, lds, tid);   // vec_rifft: bwd (-j); two transforms leave the parity even
-        store_block<C, SCALED>(w, a, blk, tid);
+        store_block<C, SCALED, NT>(w, a, blk, tid);
     }
 }
 
@@ -214,7 +214,10 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     if (b.dbg & 4) b.twL = nullptr;
     const int g = aeth::tuning_int("AETH_FIR_GRID", 0);
     if (g > 0 && g < grid) grid = g;
-    hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1>), dim3(grid), dim3(C::WG), 0, stream, b);
+    if (aeth::streams_past_cache(2 * (size_t)a.n * sizeof(float2)))
+        hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true>), dim3(grid), dim3(C::WG), 0, stream, b);
+    else
+        hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false>), dim3(grid), dim3(C::WG), 0, stream, b);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

@@ -60,21 +60,38 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f)
 }
 
 // Streamed data (touched exactly once by a kernel) is accessed with the non-temporal hint: no write-allocate,
-// no retention in L2.  Measured on MI355X: element-wise kernels 5.9 -> 6.5 TB/s, batched FFT 5.4 -> 5.8-6.1,
-// interpolate 5.5 -> 6.2, the fused FIR kernel -3 % launch time.
-template <typename V> __device__ __forceinline__ V nt_load(const V *p)
+// no retention in L2 / Infinity Cache.  Measured on MI355X with 256 MiB operands: element-wise kernels 5.9 -> 6.5
+// TB/s, batched FFT 5.4 -> 5.8-6.1, interpolate 5.5 -> 6.2, the fused FIR kernel -3 % launch time.  A chain of
+// kernels over an operand that FITS the 256 MiB cache wants the opposite (C4's 64 MiB channel: 107 GS/s with
+// plain accesses, 96 with the hint), so the hint is a kernel template parameter picked per launch by size.
+template <bool NT, typename V> __device__ __forceinline__ V nt_load(const V *p)
 {
     static_assert(sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 16, "4-, 8- or 16-byte accesses");
-    typedef unsigned VT __attribute__((ext_vector_type(sizeof(V) / 4)));
-    if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p)));
-    else return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const VT *>(p)));
+    if constexpr (!NT) return *p;
+    else {
+        typedef unsigned VT __attribute__((ext_vector_type(sizeof(V) / 4)));
+        if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p)));
+        else return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const VT *>(p)));
+    }
 }
-template <typename V> __device__ __forceinline__ void nt_store(V *p, V v)
+template <bool NT, typename V> __device__ __forceinline__ void nt_store(V *p, V v)
 {
     static_assert(sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 16, "4-, 8- or 16-byte accesses");
-    typedef unsigned VT __attribute__((ext_vector_type(sizeof(V) / 4)));
-    if constexpr (sizeof(V) == 4) __builtin_nontemporal_store(__builtin_bit_cast(unsigned, v), reinterpret_cast<unsigned *>(p));
-    else __builtin_nontemporal_store(__builtin_bit_cast(VT, v), reinterpret_cast<VT *>(p));
+    if constexpr (!NT) *p = v;
+    else {
+        typedef unsigned VT __attribute__((ext_vector_type(sizeof(V) / 4)));
+        if constexpr (sizeof(V) == 4) __builtin_nontemporal_store(__builtin_bit_cast(unsigned, v), reinterpret_cast<unsigned *>(p));
+        else __builtin_nontemporal_store(__builtin_bit_cast(VT, v), reinterpret_cast<VT *>(p));
+    }
+}
+
+// does a launch that moves `bytes` stream past the cache?  (half the 256 MiB Infinity Cache; AETH_NT=0/1 forces it
+// under AETH_TUNING=1)
+inline bool streams_past_cache(size_t bytes)
+{
+    const int forced = tuning_int("AETH_NT", -1);
+    if (forced >= 0) return forced != 0;
+    return bytes > ((size_t)128 << 20);
 }
 
 struct DeviceGuard {

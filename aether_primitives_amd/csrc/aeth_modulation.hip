@@ -42,7 +42,7 @@ __device__ __forceinline__ unsigned nearest(float2 v, const Table4 &t, int ncand
 
 // Four input bytes and 16-byte stores per lane where the alignment allows (VEC): these
 // kernels move 10 B per symbol and are store- (modulate) or load-bound (demod).
-template <int BPS, bool VEC>
+template <int BPS, bool VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restrict__ bits, float2 *__restrict__ out,
                                                           size_t nsym, Table4 t)
 {
@@ -51,14 +51,14 @@ __global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restr
         constexpr int SPL = 4 / BPS;                     // symbols per lane: 4 bytes of bits
         const size_t s0 = i * SPL;
         if (s0 >= nsym) return;
-        const uchar4 b = aeth::nt_load(reinterpret_cast<const uchar4 *>(bits) + i);
+        const uchar4 b = aeth::nt_load<NT>(reinterpret_cast<const uchar4 *>(bits) + i);
         if constexpr (BPS == 2) {
             const float2 a = pick(t, qpsk_index(b.x, b.y)), c = pick(t, qpsk_index(b.z, b.w));
-            aeth::nt_store(reinterpret_cast<float4 *>(out) + i, make_float4(a.x, a.y, c.x, c.y));
+            aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + i, make_float4(a.x, a.y, c.x, c.y));
         } else {
             const float2 a = pick(t, b.x & 1u), c = pick(t, b.y & 1u), d = pick(t, b.z & 1u), e = pick(t, b.w & 1u);   // modulation.rs:9-12
-            aeth::nt_store(reinterpret_cast<float4 *>(out) + 2 * i, make_float4(a.x, a.y, c.x, c.y));
-            aeth::nt_store(reinterpret_cast<float4 *>(out) + 2 * i + 1, make_float4(d.x, d.y, e.x, e.y));
+            aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + 2 * i, make_float4(a.x, a.y, c.x, c.y));
+            aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + 2 * i + 1, make_float4(d.x, d.y, e.x, e.y));
         }
     } else {
         if (i >= nsym) return;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restr
     }
 }
 
-template <int BPS, bool VEC>
+template <int BPS, bool VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void demod_kernel(const float2 *__restrict__ sym, uint8_t *__restrict__ bits,
                                                        size_t nsym, Table4 t, int compat)
 {
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(kBlock) void demod_kernel(const float2 *__restrict_
         constexpr int SPL = 4 / BPS;
         if (i * SPL >= nsym) return;
         if constexpr (BPS == 2) {
-            const float4 v = aeth::nt_load(reinterpret_cast<const float4 *>(sym) + i);
+            const float4 v = aeth::nt_load<NT>(reinterpret_cast<const float4 *>(sym) + i);
             const unsigned a = nearest(make_float2(v.x, v.y), t, NC), c = nearest(make_float2(v.z, v.w), t, NC);
-            aeth::nt_store(reinterpret_cast<uchar4 *>(bits) + i, make_uchar4((uint8_t)(a & 1u), hi(a), (uint8_t)(c & 1u), hi(c)));
+            aeth::nt_store<NT>(reinterpret_cast<uchar4 *>(bits) + i, make_uchar4((uint8_t)(a & 1u), hi(a), (uint8_t)(c & 1u), hi(c)));
         } else {
-            const float4 v = aeth::nt_load(reinterpret_cast<const float4 *>(sym) + 2 * i), w = aeth::nt_load(reinterpret_cast<const float4 *>(sym) + 2 * i + 1);
+            const float4 v = aeth::nt_load<NT>(reinterpret_cast<const float4 *>(sym) + 2 * i), w = aeth::nt_load<NT>(reinterpret_cast<const float4 *>(sym) + 2 * i + 1);
             reinterpret_cast<uchar4 *>(bits)[i] = make_uchar4((uint8_t)(nearest(make_float2(v.x, v.y), t, NC) & 1u),
                                                               (uint8_t)(nearest(make_float2(v.z, v.w), t, NC) & 1u),
                                                               (uint8_t)(nearest(make_float2(w.x, w.y), t, NC) & 1u),
@@ -129,10 +129,17 @@ int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, con
     const size_t spl = 4 / (size_t)bps;
     const bool vec = aeth::aligned16(out) && ((uintptr_t)bits % 4) == 0 && (n_out % spl) == 0;
     const dim3 gv(grid_for(n_out / spl)), gs(grid_for(n_out)), b(kBlock);
-    if (bps == 1 && vec)       hipLaunchKernelGGL((modulate_kernel<1, true>),  gv, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
-    else if (bps == 1)         hipLaunchKernelGGL((modulate_kernel<1, false>), gs, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
-    else if (vec)              hipLaunchKernelGGL((modulate_kernel<2, true>),  gv, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
-    else                       hipLaunchKernelGGL((modulate_kernel<2, false>), gs, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);
+    const bool nt = aeth::streams_past_cache(n_out * sizeof(float2));
+#define AETH_MOD(B, V, G)                                                                                                 \
+    do {                                                                                                                  \
+        if (nt) hipLaunchKernelGGL((modulate_kernel<B, V, true>), G, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);   \
+        else hipLaunchKernelGGL((modulate_kernel<B, V, false>), G, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);     \
+    } while (0)
+    if (bps == 1 && vec) AETH_MOD(1, true, gv);
+    else if (bps == 1)   AETH_MOD(1, false, gs);
+    else if (vec)        AETH_MOD(2, true, gv);
+    else                 AETH_MOD(2, false, gs);
+#undef AETH_MOD
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -151,10 +158,17 @@ int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym, size_t nsym, int bps, 
     const size_t spl = 4 / (size_t)bps;
     const bool vec = aeth::aligned16(sym) && ((uintptr_t)bits % 4) == 0 && (nsym % spl) == 0;
     const dim3 gv(grid_for(nsym / spl)), gs(grid_for(nsym)), b(kBlock);
-    if (bps == 1 && vec)       hipLaunchKernelGGL((demod_kernel<1, true>),  gv, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
-    else if (bps == 1)         hipLaunchKernelGGL((demod_kernel<1, false>), gs, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
-    else if (vec)              hipLaunchKernelGGL((demod_kernel<2, true>),  gv, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
-    else                       hipLaunchKernelGGL((demod_kernel<2, false>), gs, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);
+    const bool nt = aeth::streams_past_cache(nsym * sizeof(float2));
+#define AETH_DEM(B, V, G)                                                                                                         \
+    do {                                                                                                                          \
+        if (nt) hipLaunchKernelGGL((demod_kernel<B, V, true>), G, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);  \
+        else hipLaunchKernelGGL((demod_kernel<B, V, false>), G, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);    \
+    } while (0)
+    if (bps == 1 && vec) AETH_DEM(1, true, gv);
+    else if (bps == 1)   AETH_DEM(1, false, gs);
+    else if (vec)        AETH_DEM(2, true, gv);
+    else                 AETH_DEM(2, false, gs);
+#undef AETH_DEM
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

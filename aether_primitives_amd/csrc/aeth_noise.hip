@@ -18,6 +18,7 @@ namespace {
 
 constexpr int kBlock = 256;
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__ x, size_t n, float scale,
                                                             uint64_t seed, uint64_t offset, int wide)
 {
@@ -37,12 +38,12 @@ __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__
         if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
     }
     if (wide && i0 + 1 < n) {
-        float4 v = aeth::nt_load(reinterpret_cast<float4 *>(x + i0));
+        float4 v = aeth::nt_load<NT>(reinterpret_cast<float4 *>(x + i0));
         v.x = v.x + (n0r * scale) * scale;          // noise.rs:41 then :58
         v.y = v.y + (n0i * scale) * scale;
         v.z = v.z + (n1r * scale) * scale;
         v.w = v.w + (n1i * scale) * scale;
-        aeth::nt_store(reinterpret_cast<float4 *>(x + i0), v);
+        aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), v);
     } else {
         float2 a = x[i0];
         a.x = a.x + (n0r * scale) * scale;
@@ -71,7 +72,8 @@ int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal, size_t n, float power, uin
     const float scale = sqrtf(power);                       // noise.rs:35
     aeth::DeviceGuard dev_guard(ctx->device);
     const size_t pairs = (n + 1) / 2;
-    hipLaunchKernelGGL(awgn_apply_kernel, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+    auto kern = aeth::streams_past_cache(2 * n * sizeof(float2)) ? awgn_apply_kernel<true> : awgn_apply_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
                        reinterpret_cast<float2 *>(signal), n, scale, seed, offset, aeth::aligned16(signal) ? 1 : 0);
     AETH_HIP(hipGetLastError());
     return AETH_OK;

@@ -30,7 +30,8 @@ constexpr int kBlock = 256;
 constexpr int kChunks = 4;                      // 16-byte stores per lane
 constexpr int kOutPerWG = 2 * kBlock * kChunks; // outputs per workgroup: amortises the load -> LDS -> store latency chain
 
-// 32-bit index version (total < 2^31): the common case
+// 32-bit index version (total < 2^31): the common case.  NT: outputs stored with the non-temporal hint
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void interpolate_kernel32(const float2 *__restrict__ src, float2 *__restrict__ dst,
                                                                uint32_t S, FastDiv Lo, uint32_t total, FastDiv nb1,
                                                                float div, int compat_im, int wide_store)
@@ -78,11 +79,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel32(const float2 *__r
         e = slot[q];
         fi = (float)i;
         const float2 v1 = make_float2(e.x + fi * e.z, e.y + fi * e.w);
-        if (wide_store) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4 pack = {v0.x, v0.y, v1.x, v1.y};
-            __builtin_nontemporal_store(pack, reinterpret_cast<f4 *>(dst + o));   // written once, never read back here
-        }
+        if (wide_store) aeth::nt_store<NT>(reinterpret_cast<float4 *>(dst + o), make_float4(v0.x, v0.y, v1.x, v1.y));
         else { dst[o] = v0; dst[o + 1] = v1; }
     }
 }
@@ -110,13 +107,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel64(const float2 *__r
     dst[o] = out;
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(kBlock) void downsample_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                             size_t n_dst, size_t dec)
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n_dst) {                               // *c = src[i * dec]       (sampling.rs:39-41)
-        if constexpr (sizeof(T) >= 4) aeth::nt_store(dst + i, src[i * dec]);
+        if constexpr (sizeof(T) >= 4) aeth::nt_store<NT>(dst + i, src[i * dec]);
         else dst[i] = src[i * dec];
     }
 }
@@ -149,7 +146,8 @@ int interpolate_impl(aeth_ctx *ctx, const aeth_cf32 *src, size_t S, size_t batch
         // and a partial window per frame boundary it crosses
         size_t slots = kOutPerWG / (nb + 1) + 2 * (kOutPerWG / Lo + 2) + 4;
         if (slots > (size_t)kOutPerWG + 4) slots = kOutPerWG + 4;
-        hipLaunchKernelGGL(interpolate_kernel32, g, b, slots * sizeof(float4), ctx->stream, reinterpret_cast<const float2 *>(src),
+        auto k32 = aeth::streams_past_cache(total * sizeof(float2)) ? interpolate_kernel32<true> : interpolate_kernel32<false>;
+        hipLaunchKernelGGL(k32, g, b, slots * sizeof(float4), ctx->stream, reinterpret_cast<const float2 *>(src),
                            reinterpret_cast<float2 *>(dst), (uint32_t)S, make_fastdiv((uint32_t)Lo), (uint32_t)total,
                            make_fastdiv((uint32_t)(nb + 1)), (float)(nb + 1), compat, wide);
     } else {
@@ -210,13 +208,20 @@ int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, siz
     const size_t dec = n_src / n_dst;
     aeth::DeviceGuard dev_guard(ctx->device);
     const dim3 g(grid_for(ctx, n_dst)), b(kBlock);
+    const bool nt = aeth::streams_past_cache(n_dst * elem * 2);
+#define AETH_DS(TT)                                                                                                       \
+    do {                                                                                                                  \
+        if (nt) hipLaunchKernelGGL((downsample_kernel<TT, true>), g, b, 0, ctx->stream, (const TT *)src, (TT *)dst, n_dst, dec);  \
+        else hipLaunchKernelGGL((downsample_kernel<TT, false>), g, b, 0, ctx->stream, (const TT *)src, (TT *)dst, n_dst, dec);    \
+    } while (0)
     switch (elem) {
-    case 1:  hipLaunchKernelGGL(downsample_kernel<uint8_t>,  g, b, 0, ctx->stream, (const uint8_t *)src,  (uint8_t *)dst,  n_dst, dec); break;
-    case 2:  hipLaunchKernelGGL(downsample_kernel<uint16_t>, g, b, 0, ctx->stream, (const uint16_t *)src, (uint16_t *)dst, n_dst, dec); break;
-    case 4:  hipLaunchKernelGGL(downsample_kernel<uint32_t>, g, b, 0, ctx->stream, (const uint32_t *)src, (uint32_t *)dst, n_dst, dec); break;
-    case 8:  hipLaunchKernelGGL(downsample_kernel<uint2>,    g, b, 0, ctx->stream, (const uint2 *)src,    (uint2 *)dst,    n_dst, dec); break;
-    default: hipLaunchKernelGGL(downsample_kernel<uint4>,    g, b, 0, ctx->stream, (const uint4 *)src,    (uint4 *)dst,    n_dst, dec); break;
+    case 1:  AETH_DS(uint8_t); break;
+    case 2:  AETH_DS(uint16_t); break;
+    case 4:  AETH_DS(uint32_t); break;
+    case 8:  AETH_DS(uint2); break;
+    default: AETH_DS(uint4); break;
     }
+#undef AETH_DS
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

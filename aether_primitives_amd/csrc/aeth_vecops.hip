@@ -51,20 +51,20 @@ template <int OP> constexpr bool reads_self() { return OP != OP_CLONE && OP != O
 template <int OP> constexpr bool reads_other() { return OP == OP_ADD || OP == OP_SUB || OP == OP_MUL || OP == OP_DIV || OP == OP_CLONE; }
 
 // V = float4 (two samples) or float2 (one sample)
-template <int OP, typename V>
+template <int OP, typename V, bool NT>
 __global__ __launch_bounds__(kBlock) void ew_kernel(V *__restrict__ self, const V *__restrict__ other,
                                                     size_t n, float s)
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    // every element is touched exactly once: non-temporal accesses (aeth_internal.h)
+    // NT: every element is touched exactly once and the operands exceed the cache (aeth_internal.h)
     V a, b;
-    if constexpr (reads_self<OP>()) a = aeth::nt_load(self + i);
-    if constexpr (reads_other<OP>()) b = aeth::nt_load(other + i);
+    if constexpr (reads_self<OP>()) a = aeth::nt_load<NT>(self + i);
+    if constexpr (reads_other<OP>()) b = aeth::nt_load<NT>(other + i);
     V r;
     if constexpr (sizeof(V) == 16) r = apply4<OP>(a, b, s);
     else r = apply2<OP>(a, b, s);
-    aeth::nt_store(self + i, r);
+    aeth::nt_store<NT>(self + i, r);
 }
 
 inline unsigned grid_for(const aeth_ctx *, size_t items)
@@ -83,29 +83,32 @@ int launch_ew(aeth_ctx *ctx, aeth_cf32 *self, const aeth_cf32 *other, size_t n, 
     const bool two = reads_other<OP>();
     const uintptr_t ma = reinterpret_cast<uintptr_t>(a) & 15u;
     const uintptr_t mb = two ? (reinterpret_cast<uintptr_t>(b) & 15u) : ma;
+    const bool nt = aeth::streams_past_cache(n * sizeof(float2) * ((reads_self<OP>() ? 2 : 1) + (two ? 1 : 0)));
+#define AETH_EW(VV, GRID, A, B, N)                                                                                      \
+    do {                                                                                                                \
+        if (nt) hipLaunchKernelGGL((ew_kernel<OP, VV, true>), GRID, dim3(kBlock), 0, ctx->stream, A, B, N, s);          \
+        else hipLaunchKernelGGL((ew_kernel<OP, VV, false>), GRID, dim3(kBlock), 0, ctx->stream, A, B, N, s);            \
+    } while (0)
     if (ma == mb) {
         // same phase: peel one sample if the base sits on an odd 8-byte slot, then 16-byte body
         size_t head = (ma != 0 && n > 0) ? 1 : 0;
         size_t body = (n - head) / 2;
         size_t tail = (n - head) - 2 * body;
-        if (head)
-            hipLaunchKernelGGL((ew_kernel<OP, float2>), dim3(1), dim3(kBlock), 0, ctx->stream, a, b, (size_t)1, s);
+        if (head) AETH_EW(float2, dim3(1), a, b, (size_t)1);
         if (body)
-            hipLaunchKernelGGL((ew_kernel<OP, float4>), dim3(grid_for(ctx, body)), dim3(kBlock), 0, ctx->stream,
-                               reinterpret_cast<float4 *>(a + head),
-                               reinterpret_cast<const float4 *>(two ? b + head : nullptr), body, s);
-        if (tail)
-            hipLaunchKernelGGL((ew_kernel<OP, float2>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                               a + head + 2 * body, two ? b + head + 2 * body : nullptr, (size_t)1, s);
+            AETH_EW(float4, dim3(grid_for(ctx, body)), reinterpret_cast<float4 *>(a + head),
+                    reinterpret_cast<const float4 *>(two ? b + head : nullptr), body);
+        if (tail) AETH_EW(float2, dim3(1), a + head + 2 * body, two ? b + head + 2 * body : nullptr, (size_t)1);
     } else {
-        hipLaunchKernelGGL((ew_kernel<OP, float2>), dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, a, b, n, s);
+        AETH_EW(float2, dim3(grid_for(ctx, n)), a, b, n);
     }
+#undef AETH_EW
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
 
 // ---- mirror: swap(x, x+mid), mid = len/2, per frame (vecops.rs:157-161) --------
-template <typename V>
+template <typename V, bool NT>
 __global__ __launch_bounds__(kBlock) void mirror_kernel(V *__restrict__ x, size_t frame_stride_v, size_t mid_v,
                                                         size_t batch)
 {
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(kBlock) void mirror_kernel(V *__restrict__ x, size_
     if (i >= batch * mid_v) return;
     size_t f = i / mid_v, j = i - f * mid_v;
     V *p = x + f * frame_stride_v + j;
-    V lo = aeth::nt_load(p), hi = aeth::nt_load(p + mid_v);
-    aeth::nt_store(p, hi);
-    aeth::nt_store(p + mid_v, lo);
+    V lo = aeth::nt_load<NT>(p), hi = aeth::nt_load<NT>(p + mid_v);
+    aeth::nt_store<NT>(p, hi);
+    aeth::nt_store<NT>(p + mid_v, lo);
 }
 
 int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch)
@@ -126,14 +129,16 @@ int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch
     aeth::DeviceGuard dev_guard(ctx->device);
     float2 *x = reinterpret_cast<float2 *>(self);
     const bool vec = aeth::aligned16(x) && (mid % 2 == 0) && (frame_len % 2 == 0);
+    const bool nt = aeth::streams_past_cache(2 * batch * frame_len * sizeof(float2));
     if (vec) {
         size_t total = batch * (mid / 2);
-        hipLaunchKernelGGL((mirror_kernel<float4>), dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream,
+        auto k = nt ? mirror_kernel<float4, true> : mirror_kernel<float4, false>;
+        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream,
                            reinterpret_cast<float4 *>(x), frame_len / 2, mid / 2, batch);
     } else {
         size_t total = batch * mid;
-        hipLaunchKernelGGL((mirror_kernel<float2>), dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream,
-                           x, frame_len, mid, batch);
+        auto k = nt ? mirror_kernel<float2, true> : mirror_kernel<float2, false>;
+        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, x, frame_len, mid, batch);
     }
     AETH_HIP(hipGetLastError());
     return AETH_OK;
