@@ -103,7 +103,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf
         auto ws = __builtin_amdgcn_make_buffer_rsrc(out + g * C::N, 0, C::N * 8, 0x00020000);
 #pragma unroll
         for (int m = 0; m < C::P; m++)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, NT ? 2 : 0);   // aux 2 = non-temporal
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, NT ? 18 : 0);   // aux: bit 1 = non-temporal, bit 4 = sc1 (tools/nt_modes.hip)
     }
 }
 

@@ -131,7 +131,7 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
             const int e = tid + m * C::T;
             const int off = (e >= a.ov) ? e * 8 : 0x7ffffff0;
             cf v = SCALED ? cscale_k(w[m], ss) : w[m];
-            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 2 : 0);
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 18 : 0);   // nt + sc1: streamed stores (tools/nt_modes.hip: 6.55 vs 6.43 TB/s for nt alone)
         }
     } else {
 #pragma unroll
