@@ -141,7 +141,7 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch)
 {
     constexpr int G = group_of<C>();
     const size_t grid = batch * (plan->n2 / G);
-    const bool nt = plan->len * batch * sizeof(float2) > ((size_t)96 << 20);     // beyond what the 256 MiB cache holds of x, a, X
+    const bool nt = aeth::streams_past_cache(plan->len * batch * sizeof(float2) * 4 / 3);   // from 96 MiB: x, a and X together pass the cache
     auto kern = nt ? fourstep_cols<C, S, true> : fourstep_cols<C, S, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
                        (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
@@ -155,7 +155,7 @@ int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale)
 {
     constexpr int G = group_of<C>();
     const size_t grid = batch * (plan->n1 / G);
-    const bool nt = plan->len * batch * sizeof(float2) > ((size_t)96 << 20);
+    const bool nt = aeth::streams_past_cache(plan->len * batch * sizeof(float2) * 4 / 3);
     auto kern = nt ? fourstep_rows<C, S, true> : fourstep_rows<C, S, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
                        (const cf *)plan->work_dev, (cf *)out, (const cf *)plan->sub2->tw_lane_dev, (int)plan->n1,
