@@ -95,3 +95,37 @@ def test_two_host_threads_two_contexts(oracle):
     for t in range(2):
         assert bits_equal(got[t][0], want[t][0]) and bits_equal(got[t][1], want[t][1])
     c0.close()
+
+
+def test_plans_release_their_device_memory(ctx, oracle):
+    """create / run / destroy every kind of plan many times: free device memory returns to where it was"""
+    import ctypes
+    import gc
+    hip = ctypes.CDLL("libamdhip64.so")                      # the runtime libaether_hip.so already loaded
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+    taps = oracle.synth_lowpass_taps(64, 0.25)
+
+    def cycle():
+        c = ap.Context(0)
+        for n in (2048, 1000, 6000, 65536, 4099, 8192):          # pow2, mixed, mixed in place, four-step, bluestein, 8192
+            f = HipFft(c, n, max_batch=4)
+            x = c.vec(rand_c64(n, 4 * n)); f.ifwd(x, Scale.SN); f.ibwd(x, Scale.SN)
+            del f, x
+        fir = Fir(c, taps, 2048)
+        y = fir.filter(c.vec(rand_c64(5, 1 << 16)))
+        out, _ = fir.filter_stream(rand_c64(6, 1 << 16))
+        del fir, y, out
+        c.sync(); c.close()
+        gc.collect()
+
+    cycle()
+    free0 = free_bytes()
+    for _ in range(20):
+        cycle()
+    free1 = free_bytes()
+    assert free0 - free1 < (64 << 20), f"{(free0 - free1) >> 20} MiB lost over 20 create/destroy cycles"
