@@ -18,7 +18,7 @@ def one(pattern):
     return f[-1] if f else None
 
 
-out = {"tag": tag, "command": "python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline"}
+out = {"tag": tag, "command": "python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-two-queues"}
 st = one("trace/*/*_kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
