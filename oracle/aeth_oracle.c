@@ -579,7 +579,7 @@ void orc_synth_lowpass_taps(size_t ntaps, double cutoff, orc_cf32 *taps)
     for (size_t k = 0; k < ntaps; k++) {
         double m = (double)k - (double)(ntaps - 1) / 2.0;
         double sinc = (m == 0.0) ? 2.0 * cutoff : sin(2.0 * M_PI * cutoff * m) / (M_PI * m);
-        double w = 0.54 - 0.46 * cos(2.0 * M_PI * (double)k / (double)(ntaps - 1));
+        double w = ntaps > 1 ? 0.54 - 0.46 * cos(2.0 * M_PI * (double)k / (double)(ntaps - 1)) : 1.0;   /* one tap: no window */
         t[k] = sinc * w; sum += t[k];
     }
     for (size_t k = 0; k < ntaps; k++) { taps[k].re = (float)(t[k] / sum); taps[k].im = 0.0f; }

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Soak: randomized FFT / FIR / element-wise cases against the oracle for a given number of seconds, one
+process.  Prints a progress line every ~20 s; exits non-zero on the first mismatch."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import aether_primitives_amd as ap
+from aether_primitives_amd import HipFft, Fir, Scale
+from oracle import pyoracle as orc
+from helpers import rand_c64, bits_equal
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+ctx = ap.Context(0)
+lengths = [2 ** k for k in range(1, 17)] + [3, 5, 6, 7, 12, 15, 20, 60, 100, 120, 200, 360, 500, 1000, 1200, 1536, 3000, 3072,
+                                            5000, 6000, 8000, 17, 67, 127, 257, 1009, 4099, 6561, 2401]
+plans, firs = {}, {}
+t0 = last = time.time(); it = 0; worst = -400.0
+while time.time() - t0 < secs:
+    it += 1
+    kind = rng.integers(3)
+    if kind == 0:                                            # FFT, random batch / sign / scale / placement
+        n = int(rng.choice(lengths)); batch = int(rng.choice([1, 2, 3, 7, 16, 33, 128]))
+        if n * batch > (1 << 22): batch = max(1, (1 << 22) // n)
+        sign = int(rng.choice([-1, 1])); s = [Scale.NONE, Scale.SN, Scale.N, Scale.X(0.25)][int(rng.integers(4))]
+        if n not in plans: plans[n] = HipFft(ctx, n, max_batch=128)
+        x = rand_c64(int(rng.integers(1 << 30)), n * batch)
+        d = ctx.vec(x)
+        if rng.integers(2): plans[n].exec(d, d, sign, s); got = d.to_host()
+        else: o = ctx.empty(n * batch); plans[n].exec(d, o, sign, s); got = o.to_host()
+        fac = orc.scale_factor(s.kind, n, s.x)
+        ref = np.concatenate([orc.fft_f64(x[i * n:(i + 1) * n].astype(np.complex128), sign) for i in range(batch)]) * fac
+        e = orc.evm_db(got, ref); worst = max(worst, e)
+        if not e <= -115.0: print(f"FFT mismatch n={n} batch={batch} sign={sign} scale={s}: EVM {e:.1f} dB"); sys.exit(1)
+    elif kind == 1:                                          # FIR, random geometry and length
+        fft_len = int(rng.choice([256, 512, 1024, 2048, 4096])); ntaps = int(rng.choice([1, 2, 8, 33, 64, fft_len // 4]))
+        key = (fft_len, ntaps)
+        taps = orc.synth_lowpass_taps(ntaps, 0.2)
+        if key not in firs: firs[key] = Fir(ctx, taps, fft_len)
+        n = int(rng.integers(1, 1 << 19))
+        x = rand_c64(int(rng.integers(1 << 30)), n)
+        got = firs[key].filter(ctx.vec(x)).to_host()
+        ref = orc.fir_direct_f64(taps, x)
+        e = orc.evm_db(got, ref) if n >= 64 else -200.0; worst = max(worst, e)
+        if not e <= -110.0: print(f"FIR mismatch fft_len={fft_len} ntaps={ntaps} n={n}: EVM {e:.1f} dB"); sys.exit(1)
+    else:                                                    # element-wise chain, bit-exact
+        n = int(rng.integers(1, 1 << 20))
+        a, b = rand_c64(int(rng.integers(1 << 30)), n), rand_c64(int(rng.integers(1 << 30)), n) + np.complex64(2)
+        v = ctx.vec(a); v.vec_add(ctx.vec(b)).vec_mul(ctx.vec(b)).vec_conj().vec_div(ctx.vec(b)).vec_scale(0.5)
+        want = orc.vec_scale(orc.vec_div(orc.vec_conj(orc.vec_mul(orc.vec_add(a.copy(), b), b)), b), 0.5)
+        if not bits_equal(v.to_host(), want): print(f"element-wise mismatch n={n}"); sys.exit(1)
+    if time.time() - last > 20:
+        last = time.time(); print(f"{it} cases, {time.time() - t0:.0f} s, worst EVM {worst:.1f} dB", flush=True)
+print(f"soak ok: {it} cases in {time.time() - t0:.0f} s, worst EVM {worst:.1f} dB")
