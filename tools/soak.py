@@ -19,7 +19,7 @@ plans, firs = {}, {}
 t0 = last = time.time(); it = 0; worst = -400.0
 while time.time() - t0 < secs:
     it += 1
-    kind = rng.integers(3)
+    kind = rng.integers(5)
     if kind == 0:                                            # FFT, random batch / sign / scale / placement
         n = int(rng.choice(lengths)); batch = int(rng.choice([1, 2, 3, 7, 16, 33, 128]))
         if n * batch > (1 << 22): batch = max(1, (1 << 22) // n)
@@ -44,6 +44,32 @@ while time.time() - t0 < secs:
         ref = orc.fir_direct_f64(taps, x)
         e = orc.evm_db(got, ref) if n >= 64 else -200.0; worst = max(worst, e)
         if not e <= -110.0: print(f"FIR mismatch fft_len={fft_len} ntaps={ntaps} n={n}: EVM {e:.1f} dB"); sys.exit(1)
+    elif kind == 3:                                          # interpolate / downsample, bit-exact
+        from aether_primitives_amd import sampling
+        S = int(rng.integers(2, 1 << 16)); nb = int(rng.choice([0, 1, 2, 3, 9, 15, 100]))
+        src = rand_c64(int(rng.integers(1 << 30)), S)
+        dst = ctx.empty(S + (S - 1) * nb)
+        compat = bool(rng.integers(2))
+        sampling.interpolate(ctx, ctx.vec(src), dst, nb, compat_im=compat)
+        if not bits_equal(dst.to_host(), orc.interpolate(src, nb, compat_im=compat)): print(f"interpolate mismatch S={S} nb={nb}"); sys.exit(1)
+        dec = int(rng.choice([1, 2, 3, 8, 30])); nd = int(rng.integers(1, 1 << 15))
+        big = rand_c64(int(rng.integers(1 << 30)), nd * dec)
+        out = ctx.empty(nd); sampling.downsample(ctx, ctx.vec(big), out)
+        if not bits_equal(out.to_host(), big[::dec][:nd]): print(f"downsample mismatch nd={nd} dec={dec}"); sys.exit(1)
+    elif kind == 4:                                          # modulate -> awgn -> demod, bit-exact against the oracle
+        from aether_primitives_amd import modulation, noise
+        bps = int(rng.choice([1, 2])); nsym = int(rng.integers(1, 1 << 17)); seed = int(rng.integers(1 << 30))
+        bits = rng.integers(0, 2, nsym * bps, dtype=np.uint8)
+        m = modulation.qpsk(ctx) if bps == 2 else modulation.bpsk(ctx)
+        tx = m.modulate(modulation.DeviceBits(ctx, bits.size, bits))
+        ref = orc.modulate(bits, bps)
+        if not bits_equal(tx.to_host(), ref): print(f"modulate mismatch bps={bps} nsym={nsym}"); sys.exit(1)
+        noise.new(ctx, 0.04, seed).apply(tx)
+        ref = orc.awgn_apply(ref, 0.04, seed=seed)
+        if not bits_equal(tx.to_host(), ref): print(f"awgn mismatch nsym={nsym} seed={seed}"); sys.exit(1)
+        compat = bool(rng.integers(2))
+        got = m.demod_naive(tx, compat=compat).to_host()
+        if not (got == orc.demod_naive(ref, bps, compat=compat)).all(): print(f"demod mismatch bps={bps} nsym={nsym}"); sys.exit(1)
     else:                                                    # element-wise chain, bit-exact
         n = int(rng.integers(1, 1 << 20))
         a, b = rand_c64(int(rng.integers(1 << 30)), n), rand_c64(int(rng.integers(1 << 30)), n) + np.complex64(2)
