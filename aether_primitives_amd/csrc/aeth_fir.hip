@@ -85,6 +85,20 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
             return;
         }
     }
+    if constexpr (C::F > 1) {
+        // several windows per workgroup: when the whole group lies inside the stream (workgroup-uniform test)
+        // the loads need no per-element range logic, only the zeroing of the samples older than the history
+        const long long first = (blk - (long long)(threadIdx.x / C::T)) * a.hop - a.ov;
+        const long long last_end = first + (long long)(C::F - 1) * a.hop + C::N;
+        if (first >= 0 && last_end <= a.n && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
+#pragma unroll
+            for (int m = 0; m < C::P; m++) {
+                const cf v = a.in[win0 + tid + m * C::T];
+                x[m] = (tid + m * C::T >= a.ov - a.nhist) ? v : mk(0.f, 0.f);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < C::P; m++) {
         const long long gi = win0 + tid + m * C::T;
