@@ -45,7 +45,7 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
     bool par = false;
     for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const size_t frame = g * C::F + fl;
-        const bool active = frame < batch;
+        const bool active = frame < batch && (C::IDLE == 0 || fl < C::F);     // idle lanes ride along on the dummy LDS frame
         const cf *src = in + frame * C::N + tid;
         cf *dst = out + frame * C::N + tid;
         cf w[C::P];
@@ -161,6 +161,38 @@ int plan_pow2(aeth_fft *plan)
 {
 #define AETH_BODY(NN) return build_lane_table<typename CfgFor<NN>::type>(plan)
     AETH_POW2_SWITCH_XL(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
+#undef AETH_BODY
+}
+
+// lengths with factors 3 / 5 whose radices divide P: the same kernels, CfgMixFor<N>
+template <class C>
+int launch_regmix(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+{
+    const aeth_ctx *ctx = plan->ctx;
+    const bool nt = aeth::streams_past_cache(2 * batch * (size_t)C::N * sizeof(float2));
+    const size_t ngroups = (batch + C::F - 1) / C::F;
+    const size_t cap = (size_t)ctx->num_cus * (2048 / C::WG);         // fill the CU with waves: the loop has no prefetch stage
+    int grid = (int)(ngroups < cap ? ngroups : cap);
+    if (grid < 1) grid = 1;
+#define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+    if (sign > 0) { if (nt) AETH_FFT_PLAIN(+1, true); else AETH_FFT_PLAIN(+1, false); }
+    else          { if (nt) AETH_FFT_PLAIN(-1, true); else AETH_FFT_PLAIN(-1, false); }
+#undef AETH_FFT_PLAIN
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+int dispatch_regmix(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+{
+#define AETH_BODY(NN) return launch_regmix<typename CfgMixFor<NN>::type>(plan, in, out, batch, sign, scale)
+    AETH_REGMIX_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_mixed_reg: length %zu", plan->len))
+#undef AETH_BODY
+}
+
+int plan_regmix(aeth_fft *plan)
+{
+#define AETH_BODY(NN) return build_lane_table<typename CfgMixFor<NN>::type>(plan)
+    AETH_REGMIX_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_mixed_reg: length %zu", plan->len))
 #undef AETH_BODY
 }
 
@@ -557,6 +589,7 @@ int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sig
     switch (plan->algo) {
     case FFT_ALGO_POW2:  return dispatch_pow2(plan, in, out, batch, sign, scale);
     case FFT_ALGO_MIXED: return launch_mixed(plan, in, out, batch, sign, scale);
+    case FFT_ALGO_REGMIX: return dispatch_regmix(plan, in, out, batch, sign, scale);
     case FFT_ALGO_FOURSTEP: return fft_run_fourstep(plan, in, out, batch, sign, scale);
     case FFT_ALGO_BLUESTEIN: return fft_run_bluestein(plan, in, out, batch, sign, scale);
     default: return set_error(AETH_E_UNSUPPORTED, "no kernel path for length %zu", plan->len);
@@ -587,6 +620,9 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     } else if (is_pow2(len) && len <= 8192) {
         p->algo = aeth::FFT_ALGO_POW2;
         p->algo_name = "stockham_pow2";
+    } else if (regmix_supported(len) && !aeth::tuning_int("AETH_FFT_NOREGMIX", 0)) {
+        p->algo = aeth::FFT_ALGO_REGMIX;
+        p->algo_name = "stockham_mixed_reg";
     } else if (len <= 8192 && factorize_mixed(len, p->factors)) {      // two LDS images of the frame: 128 KiB at most
         p->algo = aeth::FFT_ALGO_MIXED;
         p->algo_name = "stockham_mixed";
@@ -602,6 +638,7 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     if (rc == AETH_OK) rc = make_twiddles(ctx, len, &p->tw_dev);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_POW2) rc = plan_pow2(p);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_MIXED) rc = plan_mixed(p);
+    if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_REGMIX) rc = plan_regmix(p);
     if (rc == AETH_OK) rc = aeth::fft_ensure_tmp(p, 2 * len * max_batch);
     if (rc == AETH_OK) {
         hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * len * sizeof(float2), hipHostMallocDefault);

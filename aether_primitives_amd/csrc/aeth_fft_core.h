@@ -273,15 +273,114 @@ template <int S> struct Bfly<16, S> {
     }
 };
 
+// ---- radices 3 and 5, and composite radices built from two register levels ---------------
+// (register-resident transforms of lengths with factors 3 and 5: 100 = 10*10, 1000 = 10*10*10, 1536 = 24*8*8 ...)
+constexpr double kPiD = 3.14159265358979323846264338327950288;
+constexpr double c_sin_taylor(double x)
+{
+    double term = x, sum = x;
+    for (int k = 1; k < 14; k++) { term *= -x * x / ((2 * k) * (2 * k + 1)); sum += term; }
+    return sum;
+}
+constexpr double c_sin(double x)
+{
+    while (x > kPiD) x -= 2 * kPiD;
+    while (x < -kPiD) x += 2 * kPiD;
+    if (x > kPiD / 2) x = kPiD - x;
+    if (x < -kPiD / 2) x = -kPiD - x;
+    return c_sin_taylor(x);
+}
+constexpr double c_cos(double x) { return c_sin(x + kPiD / 2); }
+
+template <int S> struct Bfly<3, S> {
+    static __device__ __forceinline__ void run(cf (&u)[3])
+    {
+        constexpr float s60 = (float)c_sin(kPiD / 3);
+        const cf t1 = cadd(u[1], u[2]), t2 = csub(u[1], u[2]);
+        const cf y0 = cadd(u[0], t1);
+        const cf h = cadd(y0, cscale_k(t1, mk(-1.5f, -1.5f)));
+        const cf jt = cscale_k(t2, mk(s60, s60));
+        u[0] = y0;
+        u[1] = cadd_rot<S>(h, jt);
+        u[2] = csub_rot<S>(h, jt);
+    }
+};
+
+template <int S> struct Bfly<5, S> {
+    static __device__ __forceinline__ void run(cf (&u)[5])
+    {
+        constexpr float cb = (float)((c_cos(2 * kPiD / 5) - c_cos(4 * kPiD / 5)) / 2);   // 0.559...
+        constexpr float s1 = (float)c_sin(2 * kPiD / 5), s2 = (float)c_sin(4 * kPiD / 5);
+        const cf t1 = cadd(u[1], u[4]), t2 = cadd(u[2], u[3]), t3 = csub(u[1], u[4]), t4 = csub(u[2], u[3]);
+        const cf t5 = cadd(t1, t2);
+        const cf y0 = cadd(u[0], t5);
+        const cf m1 = cadd(y0, cscale_k(t5, mk(-1.25f, -1.25f)));
+        const cf m2 = cscale_k(csub(t1, t2), mk(cb, cb));
+        const cf a1 = cadd(m1, m2), a2 = csub(m1, m2);
+        const cf b1 = cadd(cscale_k(t3, mk(s1, s1)), cscale_k(t4, mk(s2, s2)));
+        const cf b2 = csub(cscale_k(t3, mk(s2, s2)), cscale_k(t4, mk(s1, s1)));
+        u[0] = y0;
+        u[1] = cadd_rot<S>(a1, b1);
+        u[4] = csub_rot<S>(a1, b1);
+        u[2] = cadd_rot<S>(a2, b2);
+        u[3] = csub_rot<S>(a2, b2);
+    }
+};
+
+// R = R1*R2:  X[k1 + R1*k2] = sum_n2 W_R2^(n2 k2) [ W_R^(n2 k1) sum_n1 x[n1*R2 + n2] W_R1^(n1 k1) ]
+// the inner twiddles W_R^(n2 k1) are compile-time constants held in SGPR pairs
+template <int R1, int R2, int S> struct BflyC {
+    static __device__ __forceinline__ void run(cf (&u)[R1 * R2])
+    {
+        constexpr int R = R1 * R2;
+#pragma unroll
+        for (int n2 = 0; n2 < R2; n2++) {
+            cf t[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; n1++) t[n1] = u[n1 * R2 + n2];
+            Bfly<R1, S>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < R1; k1++) {
+                if (n2 > 0 && k1 > 0) {
+                    const double ang = 2 * kPiD * (double)((n2 * k1) % R) / (double)R;
+                    u[k1 * R2 + n2] = ctw_k<S>(t[k1], mk((float)c_cos(ang), (float)(-c_sin(ang))));
+                } else u[k1 * R2 + n2] = t[k1];
+            }
+        }
+        cf x[R];
+#pragma unroll
+        for (int k1 = 0; k1 < R1; k1++) {
+            cf t[R2];
+#pragma unroll
+            for (int n2 = 0; n2 < R2; n2++) t[n2] = u[k1 * R2 + n2];
+            Bfly<R2, S>::run(t);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; k2++) x[k1 + R1 * k2] = t[k2];
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) u[r] = x[r];
+    }
+};
+template <int S> struct Bfly<6, S>  : BflyC<3, 2, S> {};
+template <int S> struct Bfly<10, S> : BflyC<5, 2, S> {};
+template <int S> struct Bfly<12, S> : BflyC<4, 3, S> {};
+template <int S> struct Bfly<15, S> : BflyC<5, 3, S> {};
+template <int S> struct Bfly<20, S> : BflyC<5, 4, S> {};
+template <int S> struct Bfly<24, S> : BflyC<8, 3, S> {};
+template <int S> struct Bfly<25, S> : BflyC<5, 5, S> {};
+
 // ---- compile-time description of one transform size ---------------------------
-template <int N_, int P_, int R0_, int R1_ = 1, int R2_ = 1, int R3_ = 1>
+// WG_ = 0: the power-of-two rule (T lanes, at least 64).  WG_ > 0: that many lanes; F = WG / T frames, the
+// WG - F*T lanes left over idle on a dummy LDS frame (lengths whose T does not divide a wave)
+template <int N_, int P_, int R0_, int R1_ = 1, int R2_ = 1, int R3_ = 1, int WG_ = 0>
 struct Cfg {
     static constexpr int N = N_;
     static constexpr int P = P_;                 // points per lane
     static constexpr int T = N_ / P_;            // lanes per frame
     static constexpr int NPASS = (R1_ == 1) ? 1 : (R2_ == 1) ? 2 : (R3_ == 1) ? 3 : 4;
-    static constexpr int WG = (T >= 64) ? T : 64;   // workgroup size
+    static constexpr int WG = WG_ > 0 ? WG_ : (T >= 64) ? T : 64;   // workgroup size
     static constexpr int F = WG / T;                // frames per workgroup
+    static constexpr int IDLE = WG - F * T;         // lanes beyond the last whole frame
     static constexpr int radix(int s) { return s == 0 ? R0_ : s == 1 ? R1_ : s == 2 ? R2_ : R3_; }
     static constexpr int pbefore(int s)
     {
@@ -301,12 +400,13 @@ struct Cfg {
     // LDS image of one frame: one pad slot per 16 elements (kills the 16-way write
     // conflict of the first exchange, whose lanes write at stride 16 elements)
     static constexpr int LDS_FRAME = (NPASS > 1) ? (N_ + N_ / 16) : 0;
-    static constexpr int LDS_ELEMS = (LDS_FRAME * F > 0) ? LDS_FRAME * F : 1;   // one image of the workgroup's frames
+    static constexpr int LDS_ELEMS = (LDS_FRAME * F > 0) ? LDS_FRAME * (F + (IDLE > 0 ? 1 : 0)) : 1;   // one image of the workgroup's frames (+ a dummy one for idle lanes)
     static constexpr bool DB = (NPASS > 1) && (2 * LDS_ELEMS * 8 <= AETH_LDS_DB_LIMIT);   // room for two images
     static constexpr int LDS_TOTAL = DB ? 2 * LDS_ELEMS : LDS_ELEMS;
     static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
     static_assert(N_ % P_ == 0 && P_ % R0_ == 0 && P_ % R1_ == 0 && P_ % R2_ == 0 && P_ % R3_ == 0, "bad P");
-    static_assert(WG % T == 0, "frames must tile the workgroup");
+    static_assert(WG_ > 0 || WG % T == 0, "frames must tile the workgroup");
+    static_assert(F >= 1, "a frame needs T lanes");
 };
 
 __device__ __forceinline__ int lidx(int e) { return e + (e >> 4); }
@@ -319,7 +419,7 @@ __device__ __forceinline__ void load_tw_pass(cf (&tw)[C::TW], const cf *__restri
     constexpr int step = C::N / (p * R);
 #pragma unroll
     for (int b = 0; b < B; b++) {
-        const int k = (tid + b * C::T) & (p - 1);
+        const int k = (tid + b * C::T) % p;
 #pragma unroll
         for (int r = 1; r < R; r++) tw[C::twoff(PASS) + b * (R - 1) + (r - 1)] = twN[r * k * step];
     }
@@ -361,7 +461,7 @@ __device__ __forceinline__ void lane_tw_pass(cf (&tw)[C::TW], const cf *__restri
     cf *wr = const_cast<cf *>(twL);
 #pragma unroll
     for (int b = 0; b < B; b++) {
-        const int lane = (p < C::T) ? ((tid + b * C::T) & (p - 1)) : tid;
+        const int lane = (p < C::T) ? ((tid + b * C::T) % p) : tid;
 #pragma unroll
         for (int r = 1; r < R; r++) {
             const int slot = C::twoff(PASS) + b * (R - 1) + (r - 1);
@@ -422,7 +522,7 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
             for (int r = 0; r < R; r++) w[b + r * B] = u[r];
         } else {
             const int i = tid + b * C::T;
-            const int k = i & (p - 1);
+            const int k = i % p;
             const int j = (i - k) * R + k;
 #pragma unroll
             for (int r = 0; r < R; r++) img[lidx(j + r * p)] = u[r];
@@ -475,6 +575,21 @@ template <> struct CfgFor<8192> { using type = Cfg<8192, 16, 16, 16, 8, 4>; };
     case 4096: BODY(4096);                                                             \
     default: DEFAULT;                                                                  \
     }
+
+// ---- register-resident transforms of lengths with factors 3 and 5 -----------------------------
+// Same engine, radices 3/5/6/10/12/15/20/24/25 in registers; T = N/P is no power of two, so the workgroup
+// size is given and a few lanes idle.  Only lengths whose radices all divide P qualify (the rest goes through
+// the LDS ping-pong kernel): the table below is the set of such lengths worth a kernel instantiation.
+template <int N> struct CfgMixFor;
+template <> struct CfgMixFor<100>  { using type = Cfg<100, 10, 10, 10, 1, 1, 64>; };      // 6 frames of 10 lanes per wave
+template <> struct CfgMixFor<1000> { using type = Cfg<1000, 10, 10, 10, 10, 1, 512>; };   // 5 frames of 100 lanes
+
+#define AETH_REGMIX_SWITCH(len, BODY, DEFAULT)                                          \
+    switch (len) {                                                                     \
+    case 100: BODY(100); case 1000: BODY(1000);                                        \
+    default: DEFAULT;                                                                  \
+    }
+constexpr bool regmix_supported(size_t len) { return len == 100 || len == 1000; }
 
 // the same plus the lengths only the plain transform kernels are built for
 #define AETH_POW2_SWITCH_XL(len, BODY, DEFAULT)                                         \

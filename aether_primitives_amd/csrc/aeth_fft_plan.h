@@ -32,7 +32,7 @@ struct aeth_fft {
 
 namespace aeth {
 
-enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4 };
+enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_REGMIX = 5 };
 
 int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 int fft_ensure_tmp(aeth_fft *plan, size_t elems);

@@ -64,7 +64,7 @@ def test_reference_roundtrip_100(ctx):
     c.vec_fft(Scale.SN).vec_ifft(Scale.SN)
     ap.assert_evm(c.to_host(), v)
     c = ctx.vec(v); f = HipFft(ctx, 100)
-    assert f.algorithm == "stockham_mixed"
+    assert f.algorithm in ("stockham_mixed", "stockham_mixed_reg")
     c.vec_rfft(f, Scale.SN).vec_rifft(f, Scale.SN)
     ap.assert_evm(c.to_host(), v)
     h = v.copy(); ap.HostVec(ctx, h).vec_rfft(f, Scale.SN).vec_rifft(f, Scale.SN)
@@ -97,7 +97,8 @@ def test_fft_vs_truth_big(ctx, oracle, n):
 
 def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 2048).algorithm == "stockham_pow2"
-    assert HipFft(ctx, 100).algorithm == "stockham_mixed"
+    assert HipFft(ctx, 100).algorithm == "stockham_mixed_reg"
+    assert HipFft(ctx, 120).algorithm == "stockham_mixed"
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
 
