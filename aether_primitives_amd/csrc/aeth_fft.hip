@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 using namespace aeth::fftk;
@@ -28,12 +29,29 @@ using namespace aeth::fftk;
 namespace {
 
 // =============================== stockham_pow2 ================================
+// Frames of a few lanes (T < 16): a lane's points are 8*T bytes apart in memory, so direct accesses touch a
+// separate 64-byte segment per lane and instruction.  The workgroup's F frames are contiguous, so they go through
+// LDS instead: coalesced 8-byte accesses on the memory side, one pad slot per frame on the LDS side (frames would
+// otherwise sit a multiple of the bank count apart).  Needs the CU full of waves to hide the extra hop.
+template <class C> constexpr bool pow2_staged_io() { return C::T < 16 && C::F > 1 && C::IDLE > 0; }
+template <class C> struct SingleImage : C {
+    static constexpr bool DB = false;
+    static constexpr int LDS_TOTAL = C::LDS_ELEMS;
+};
+
 // NT: frames are streamed with the non-temporal hint (batches beyond the cache; aeth_internal.h)
-template <class C, int S, bool NT>
-__global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
+template <class C0, int S, bool NT>
+__global__ __launch_bounds__(C0::WG) void fft_pow2_kernel(const cf *in, cf *out,
                                                           const cf *__restrict__ twL, size_t batch, float scale)
 {
-    __shared__ cf lds_all[C::LDS_TOTAL];
+    constexpr bool STAGED = pow2_staged_io<C0>();
+    // staged configurations: ONE exchange image, and the I/O staging area shares its LDS (the image is idle
+    // while frames are copied in and out) -- LDS per workgroup is what bounds the waves per CU here
+    using C = typename std::conditional<STAGED, SingleImage<C0>, C0>::type;
+    constexpr int IO_ELEMS = STAGED ? C::F * (C::N + 1) : 0;
+    constexpr int LDS_N = C::LDS_TOTAL > IO_ELEMS ? C::LDS_TOTAL : IO_ELEMS;
+    __shared__ cf lds_all[LDS_N];
+    cf *lds_io = lds_all;
     const int tid = (C::F == 1) ? (int)threadIdx.x : (int)(threadIdx.x % C::T);
     const int fl = (C::F == 1) ? 0 : (int)(threadIdx.x / C::T);
     cf *lds = lds_all + fl * C::LDS_FRAME;
@@ -49,14 +67,50 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_kernel(const cf *in, cf *out,
         const cf *src = in + frame * C::N + tid;
         cf *dst = out + frame * C::N + tid;
         cf w[C::P];
+        const size_t base = g * C::F * (size_t)C::N;
+        const size_t left = batch * (size_t)C::N - base;                     // elements from this group to the end
+        const int have = left < (size_t)(C::F * C::N) ? (int)left : C::F * C::N;
+        if constexpr (STAGED) {
+            // all loads of the group first, then the LDS writes: one memory round trip per group, not one per line
+            constexpr int ITER = (C::F * C::N + C::WG - 1) / C::WG;
+            cf stage[ITER];
 #pragma unroll
-        for (int m = 0; m < C::P; m++) w[m] = active ? aeth::nt_load<NT>(src + m * C::T) : mk(0.f, 0.f);
+            for (int q = 0; q < ITER; q++) {
+                const int e = threadIdx.x + q * C::WG;
+                stage[q] = e < have ? aeth::nt_load<NT>(in + base + e) : mk(0.f, 0.f);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < ITER; q++) {
+                const int e = threadIdx.x + q * C::WG;
+                if (e < C::F * C::N) lds_io[e + e / C::N] = stage[q];
+            }
+            __syncthreads();
+            const int fr = fl < C::F ? fl : 0;
+#pragma unroll
+            for (int m = 0; m < C::P; m++) w[m] = lds_io[fr * (C::N + 1) + tid + m * C::T];
+        } else {
+#pragma unroll
+            for (int m = 0; m < C::P; m++) w[m] = active ? aeth::nt_load<NT>(src + m * C::T) : mk(0.f, 0.f);
+        }
         // an odd number of exchanges per transform flips the image parity every frame
         if (fft_next_par<C>(0) == 0 || !par) fft_in_regs<C, S, 0>(w, tw, lds, tid);
         else fft_in_regs<C, S, 1>(w, tw, lds, tid);
         par = (fft_next_par<C>(0) != 0) && !par;
-        if (active) {
-            const cf ss = mk(scale, scale);
+        const cf ss = mk(scale, scale);
+        if constexpr (STAGED) {
+            __syncthreads();
+            if (fl < C::F) {
+#pragma unroll
+                for (int m = 0; m < C::P; m++) lds_io[fl * (C::N + 1) + tid + m * C::T] = cscale_k(w[m], ss);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (C::F * C::N + C::WG - 1) / C::WG; q++) {
+                const int e = threadIdx.x + q * C::WG;
+                if (e < have) aeth::nt_store<NT>(out + base + e, lds_io[e + e / C::N]);
+            }
+        } else if (active) {
 #pragma unroll
             for (int m = 0; m < C::P; m++) aeth::nt_store<NT>(dst + m * C::T, cscale_k(w[m], ss));
         }

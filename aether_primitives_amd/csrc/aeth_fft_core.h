@@ -581,7 +581,7 @@ template <> struct CfgFor<8192> { using type = Cfg<8192, 16, 16, 16, 8, 4>; };
 // size is given and a few lanes idle.  Only lengths whose radices all divide P qualify (the rest goes through
 // the LDS ping-pong kernel): the table below is the set of such lengths worth a kernel instantiation.
 template <int N> struct CfgMixFor;
-template <> struct CfgMixFor<100>  { using type = Cfg<100, 10, 10, 10, 1, 1, 64>; };      // 6 frames of 10 lanes per wave
+template <> struct CfgMixFor<100>  { using type = Cfg<100, 10, 10, 10, 1, 1, 256>; };     // 25 frames of 10 lanes
 template <> struct CfgMixFor<1000> { using type = Cfg<1000, 10, 10, 10, 10, 1, 512>; };   // 5 frames of 100 lanes
 
 #define AETH_REGMIX_SWITCH(len, BODY, DEFAULT)                                          \
