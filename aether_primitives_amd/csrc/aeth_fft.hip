@@ -33,7 +33,7 @@ namespace {
 // separate 64-byte segment per lane and instruction.  The workgroup's F frames are contiguous, so they go through
 // LDS instead: coalesced 8-byte accesses on the memory side, one pad slot per frame on the LDS side (frames would
 // otherwise sit a multiple of the bank count apart).  Needs the CU full of waves to hide the extra hop.
-template <class C> constexpr bool pow2_staged_io() { return C::T < 16 && C::F > 1 && C::IDLE > 0; }
+template <class C> constexpr bool pow2_staged_io() { return C::T < 16 && C::F > 1 && C::N >= 4; }
 template <class C> struct SingleImage : C {
     static constexpr bool DB = false;
     static constexpr int LDS_TOTAL = C::LDS_ELEMS;
