@@ -52,8 +52,9 @@ __global__ __launch_bounds__(C0::WG) void fft_pow2_kernel(const cf *in, cf *out,
     constexpr int LDS_N = C::LDS_TOTAL > IO_ELEMS ? C::LDS_TOTAL : IO_ELEMS;
     __shared__ cf lds_all[LDS_N];
     cf *lds_io = lds_all;
-    const int tid = (C::F == 1) ? (int)threadIdx.x : (int)(threadIdx.x % C::T);
-    const int fl = (C::F == 1) ? 0 : (int)(threadIdx.x / C::T);
+    constexpr bool WHOLE = C::F == 1 && C::IDLE == 0;       // the workgroup is exactly one frame
+    const int tid = WHOLE ? (int)threadIdx.x : (int)(threadIdx.x % C::T);
+    const int fl = WHOLE ? 0 : (int)(threadIdx.x / C::T);   // idle lanes: fl == F, the dummy LDS frame
     cf *lds = lds_all + fl * C::LDS_FRAME;
 
     cf tw[C::TW];
@@ -224,14 +225,25 @@ int launch_regmix(const aeth_fft *plan, const float2 *in, float2 *out, size_t ba
 {
     const aeth_ctx *ctx = plan->ctx;
     const bool nt = aeth::streams_past_cache(2 * batch * (size_t)C::N * sizeof(float2));
-    const size_t ngroups = (batch + C::F - 1) / C::F;
-    const size_t cap = (size_t)ctx->num_cus * (2048 / C::WG);         // fill the CU with waves: the loop has no prefetch stage
-    int grid = (int)(ngroups < cap ? ngroups : cap);
-    if (grid < 1) grid = 1;
+    if constexpr (C::F == 1 && C::IDLE == 0 && C::P <= 16) {
+        // a whole number of waves per frame and registers to spare: the descriptor / prefetch pipeline of the power-of-two kernels
+        size_t cap2 = (size_t)ctx->num_cus * (512 / C::WG);
+        int grid2 = (int)(batch < cap2 ? batch : cap2);
+        if (grid2 < 1) grid2 = 1;
+#define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+        if (sign > 0) { if (nt) AETH_FFT_STREAM(+1, true); else AETH_FFT_STREAM(+1, false); }
+        else          { if (nt) AETH_FFT_STREAM(-1, true); else AETH_FFT_STREAM(-1, false); }
+#undef AETH_FFT_STREAM
+    } else {
+        const size_t ngroups = (batch + C::F - 1) / C::F;
+        const size_t cap = (size_t)ctx->num_cus * (2048 / C::WG);     // fill the CU with waves: the loop has no prefetch stage
+        int grid = (int)(ngroups < cap ? ngroups : cap);
+        if (grid < 1) grid = 1;
 #define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
-    if (sign > 0) { if (nt) AETH_FFT_PLAIN(+1, true); else AETH_FFT_PLAIN(+1, false); }
-    else          { if (nt) AETH_FFT_PLAIN(-1, true); else AETH_FFT_PLAIN(-1, false); }
+        if (sign > 0) { if (nt) AETH_FFT_PLAIN(+1, true); else AETH_FFT_PLAIN(+1, false); }
+        else          { if (nt) AETH_FFT_PLAIN(-1, true); else AETH_FFT_PLAIN(-1, false); }
 #undef AETH_FFT_PLAIN
+    }
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

@@ -581,15 +581,51 @@ template <> struct CfgFor<8192> { using type = Cfg<8192, 16, 16, 16, 8, 4>; };
 // size is given and a few lanes idle.  Only lengths whose radices all divide P qualify (the rest goes through
 // the LDS ping-pong kernel): the table below is the set of such lengths worth a kernel instantiation.
 template <int N> struct CfgMixFor;
-template <> struct CfgMixFor<100>  { using type = Cfg<100, 10, 10, 10, 1, 1, 256>; };     // 25 frames of 10 lanes
-template <> struct CfgMixFor<1000> { using type = Cfg<1000, 10, 10, 10, 10, 1, 512>; };   // 5 frames of 100 lanes
+template <> struct CfgMixFor<96> { using type = Cfg<96, 24, 24, 4, 1, 1, 64>; };
+template <> struct CfgMixFor<100> { using type = Cfg<100, 10, 10, 10, 1, 1, 256>; };
+template <> struct CfgMixFor<144> { using type = Cfg<144, 12, 12, 12, 1, 1, 192>; };
+template <> struct CfgMixFor<192> { using type = Cfg<192, 24, 24, 8, 1, 1, 64>; };
+template <> struct CfgMixFor<200> { using type = Cfg<200, 20, 20, 10, 1, 1, 320>; };
+template <> struct CfgMixFor<288> { using type = Cfg<288, 24, 24, 12, 1, 1, 192>; };
+template <> struct CfgMixFor<384> { using type = Cfg<384, 24, 24, 8, 2, 1, 64>; };
+template <> struct CfgMixFor<400> { using type = Cfg<400, 20, 20, 20, 1, 1, 320>; };
+template <> struct CfgMixFor<500> { using type = Cfg<500, 10, 10, 10, 5, 1, 256>; };
+template <> struct CfgMixFor<576> { using type = Cfg<576, 24, 24, 24, 1, 1, 192>; };
+template <> struct CfgMixFor<625> { using type = Cfg<625, 25, 25, 25, 1, 1, 128>; };
+template <> struct CfgMixFor<768> { using type = Cfg<768, 24, 24, 8, 4, 1, 64>; };
+template <> struct CfgMixFor<800> { using type = Cfg<800, 20, 20, 20, 2, 1, 320>; };
+template <> struct CfgMixFor<1000> { using type = Cfg<1000, 10, 10, 10, 10, 1, 512>; };
+template <> struct CfgMixFor<1152> { using type = Cfg<1152, 24, 24, 24, 2, 1, 192>; };
+template <> struct CfgMixFor<1536> { using type = Cfg<1536, 24, 24, 8, 8, 1, 64>; };
+template <> struct CfgMixFor<1600> { using type = Cfg<1600, 20, 20, 20, 4, 1, 320>; };
+template <> struct CfgMixFor<2000> { using type = Cfg<2000, 20, 20, 20, 5, 1, 320>; };
+template <> struct CfgMixFor<2304> { using type = Cfg<2304, 24, 24, 24, 4, 1, 192>; };
+template <> struct CfgMixFor<2500> { using type = Cfg<2500, 10, 10, 10, 5, 5, 256>; };
+template <> struct CfgMixFor<3072> { using type = Cfg<3072, 24, 24, 8, 8, 2, 128>; };
+template <> struct CfgMixFor<4000> { using type = Cfg<4000, 20, 20, 20, 10, 1, 448>; };
+template <> struct CfgMixFor<4608> { using type = Cfg<4608, 24, 24, 24, 8, 1, 192>; };
+template <> struct CfgMixFor<5000> { using type = Cfg<5000, 10, 10, 10, 10, 5, 512>; };
+template <> struct CfgMixFor<6144> { using type = Cfg<6144, 24, 24, 8, 8, 4, 256>; };
 
 #define AETH_REGMIX_SWITCH(len, BODY, DEFAULT)                                          \
     switch (len) {                                                                     \
-    case 100: BODY(100); case 1000: BODY(1000);                                        \
+    case 96: BODY(96); case 100: BODY(100); case 144: BODY(144); case 192: BODY(192);  \
+    case 200: BODY(200); case 288: BODY(288); case 384: BODY(384); case 400: BODY(400);\
+    case 500: BODY(500); case 576: BODY(576); case 625: BODY(625); case 768: BODY(768);\
+    case 800: BODY(800); case 1000: BODY(1000); case 1152: BODY(1152); case 1536: BODY(1536);\
+    case 1600: BODY(1600); case 2000: BODY(2000); case 2304: BODY(2304); case 2500: BODY(2500);\
+    case 3072: BODY(3072); case 4000: BODY(4000); case 4608: BODY(4608); case 5000: BODY(5000);\
+    case 6144: BODY(6144);                                                             \
     default: DEFAULT;                                                                  \
     }
-constexpr bool regmix_supported(size_t len) { return len == 100 || len == 1000; }
+constexpr bool regmix_supported(size_t len)
+{
+    switch (len) {
+    case 96: case 100: case 144: case 192: case 200: case 288: case 384: case 400: case 500: case 576: case 625: case 768: case 800: case 1000: case 1152: case 1536: case 1600: case 2000: case 2304: case 2500: case 3072: case 4000: case 4608: case 5000: case 6144:
+        return true;
+    default: return false;
+    }
+}
 
 // the same plus the lengths only the plain transform kernels are built for
 #define AETH_POW2_SWITCH_XL(len, BODY, DEFAULT)                                         \

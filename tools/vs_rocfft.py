@@ -54,7 +54,8 @@ ys = [torch.empty_like(xs[0]) for _ in range(3)]
 mine = [ctx.vec(host) for _ in range(3)]
 mine_out = [ctx.empty(total) for _ in range(3)]
 print(f"{'case':44s} {'hipFFT / rocFFT':>22s} {'this library':>22s}   ratio")
-for N in (100, 512, 1000, 1024, 2048, 4096, 8192, 65536):
+sizes = [int(a) for a in sys.argv[1:]] or [100, 512, 1000, 1024, 2048, 4096, 8192, 65536]
+for N in sizes:
     m = (total // N) * N; batch = m // N
     k = [0]
     vp = VendorPlan(N, batch)
@@ -65,6 +66,7 @@ for N in (100, 512, 1000, 1024, 2048, 4096, 8192, 65536):
     def f_m(i): f.bwd(mine[i % 3].slice(0, m), mine_out[i % 3].slice(0, m), Scale.NONE)      # -j exponent, like torch.fft.fft
     a, b = t_torch(f_t), t_mine(f_m)
     print(f"fft N={N:6d} x {batch:7d} out of place".ljust(44) + f" {a*1e3:8.1f} us {16*m/a/1e9:6.2f} TB/s  {b*1e3:8.1f} us {16*m/b/1e9:6.2f} TB/s   {a/b:5.2f}x", flush=True)
+if len(sys.argv) > 1: sys.exit(0)
 # transform * filter * inverse on 2048-point frames (the correlator chain / one overlap-save block per frame)
 N = 2048; batch = total // N
 H = torch.from_numpy((rng.standard_normal(2 * N, dtype=np.float32)).view(np.complex64)).to(dev)
