@@ -29,11 +29,15 @@ using namespace aeth::fftk;
 namespace {
 
 // =============================== stockham_pow2 ================================
-// Frames of a few lanes (T < 16): a lane's points are 8*T bytes apart in memory, so direct accesses touch a
+#ifndef AETH_STAGE_T
+#define AETH_STAGE_T 24
+#endif
+
+// Frames of a few lanes (T < AETH_STAGE_T): a lane's points are 8*T bytes apart in memory, so direct accesses touch a
 // separate 64-byte segment per lane and instruction.  The workgroup's F frames are contiguous, so they go through
 // LDS instead: coalesced 8-byte accesses on the memory side, one pad slot per frame on the LDS side (frames would
 // otherwise sit a multiple of the bank count apart).  Needs the CU full of waves to hide the extra hop.
-template <class C> constexpr bool pow2_staged_io() { return C::T < 16 && C::F > 1 && C::N >= 4; }
+template <class C> constexpr bool pow2_staged_io() { return C::T < AETH_STAGE_T && C::F > 1 && C::N >= 4; }
 template <class C> struct SingleImage : C {
     static constexpr bool DB = false;
     static constexpr int LDS_TOTAL = C::LDS_ELEMS;

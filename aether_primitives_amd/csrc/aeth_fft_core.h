@@ -585,10 +585,10 @@ template <> struct CfgMixFor<96> { using type = Cfg<96, 24, 24, 4, 1, 1, 64>; };
 template <> struct CfgMixFor<100> { using type = Cfg<100, 10, 10, 10, 1, 1, 256>; };
 template <> struct CfgMixFor<144> { using type = Cfg<144, 12, 12, 12, 1, 1, 192>; };
 template <> struct CfgMixFor<192> { using type = Cfg<192, 24, 24, 8, 1, 1, 64>; };
-template <> struct CfgMixFor<200> { using type = Cfg<200, 20, 20, 10, 1, 1, 320>; };
+template <> struct CfgMixFor<200> { using type = Cfg<200, 10, 10, 10, 2, 1, 320>; };
 template <> struct CfgMixFor<288> { using type = Cfg<288, 24, 24, 12, 1, 1, 192>; };
 template <> struct CfgMixFor<384> { using type = Cfg<384, 24, 24, 8, 2, 1, 64>; };
-template <> struct CfgMixFor<400> { using type = Cfg<400, 20, 20, 20, 1, 1, 320>; };
+template <> struct CfgMixFor<400> { using type = Cfg<400, 10, 10, 10, 2, 2, 320>; };
 template <> struct CfgMixFor<500> { using type = Cfg<500, 10, 10, 10, 5, 1, 256>; };
 template <> struct CfgMixFor<576> { using type = Cfg<576, 24, 24, 24, 1, 1, 192>; };
 template <> struct CfgMixFor<625> { using type = Cfg<625, 25, 25, 25, 1, 1, 128>; };
