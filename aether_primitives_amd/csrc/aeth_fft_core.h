@@ -607,6 +607,20 @@ template <> struct CfgMixFor<4608> { using type = Cfg<4608, 24, 24, 24, 8, 1, 19
 template <> struct CfgMixFor<5000> { using type = Cfg<5000, 10, 10, 10, 10, 5, 512>; };
 template <> struct CfgMixFor<6144> { using type = Cfg<6144, 24, 24, 8, 8, 4, 256>; };
 
+template <> struct CfgMixFor<120> { using type = Cfg<120, 30, 10, 6, 2, 1, 64>; };
+template <> struct CfgMixFor<600> { using type = Cfg<600, 30, 10, 10, 6, 1, 64>; };
+template <> struct CfgMixFor<1200> { using type = Cfg<1200, 30, 10, 10, 6, 2, 128>; };
+template <> struct CfgMixFor<3000> { using type = Cfg<3000, 30, 15, 10, 10, 2, 128>; };
+template <> struct CfgMixFor<240> { using type = Cfg<240, 30, 10, 6, 2, 2, 64>; };
+template <> struct CfgMixFor<300> { using type = Cfg<300, 30, 15, 10, 2, 1, 64>; };
+template <> struct CfgMixFor<360> { using type = Cfg<360, 30, 10, 6, 6, 1, 64>; };
+template <> struct CfgMixFor<720> { using type = Cfg<720, 30, 10, 6, 6, 2, 64>; };
+template <> struct CfgMixFor<900> { using type = Cfg<900, 30, 15, 10, 6, 1, 64>; };
+template <> struct CfgMixFor<1500> { using type = Cfg<1500, 30, 15, 10, 10, 1, 256>; };
+template <> struct CfgMixFor<1800> { using type = Cfg<1800, 30, 15, 10, 6, 2, 128>; };
+template <> struct CfgMixFor<3600> { using type = Cfg<3600, 30, 10, 10, 6, 6, 128>; };
+template <> struct CfgMixFor<6000> { using type = Cfg<6000, 30, 10, 10, 10, 6, 256>; };
+
 #define AETH_REGMIX_SWITCH(len, BODY, DEFAULT)                                          \
     switch (len) {                                                                     \
     case 96: BODY(96); case 100: BODY(100); case 144: BODY(144); case 192: BODY(192);  \
@@ -616,12 +630,17 @@ template <> struct CfgMixFor<6144> { using type = Cfg<6144, 24, 24, 8, 8, 4, 256
     case 1600: BODY(1600); case 2000: BODY(2000); case 2304: BODY(2304); case 2500: BODY(2500);\
     case 3072: BODY(3072); case 4000: BODY(4000); case 4608: BODY(4608); case 5000: BODY(5000);\
     case 6144: BODY(6144);                                                             \
+    case 120: BODY(120); case 600: BODY(600); case 1200: BODY(1200); case 3000: BODY(3000);  \
+    case 240: BODY(240); case 300: BODY(300); case 360: BODY(360); case 720: BODY(720); case 900: BODY(900); \
+    case 1500: BODY(1500); case 1800: BODY(1800); case 3600: BODY(3600); case 6000: BODY(6000); \
     default: DEFAULT;                                                                  \
     }
 constexpr bool regmix_supported(size_t len)
 {
     switch (len) {
     case 96: case 100: case 144: case 192: case 200: case 288: case 384: case 400: case 500: case 576: case 625: case 768: case 800: case 1000: case 1152: case 1536: case 1600: case 2000: case 2304: case 2500: case 3072: case 4000: case 4608: case 5000: case 6144:
+    case 120: case 600: case 1200: case 3000: case 240: case 300: case 360: case 720: case 900: case 1500: case 1800:
+    case 3600: case 6000:
         return true;
     default: return false;
     }

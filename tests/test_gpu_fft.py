@@ -21,8 +21,9 @@ TOL_DB = -120.0
 
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 MIXED = [1, 3, 5, 6, 7, 9, 10, 12, 15, 20, 25, 49, 60, 61, 100, 120, 210, 1000, 1155, 3125, 4095,
-         96, 144, 192, 200, 288, 384, 400, 500, 576, 625, 768, 800, 1152, 1536, 1600, 2000, 2304, 2500, 3072]   # register-resident table
-BIG = [4000, 4608, 5000, 6144, 8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
+         96, 144, 192, 200, 288, 384, 400, 500, 576, 625, 768, 800, 1152, 1536, 1600, 2000, 2304, 2500, 3072,
+         240, 300, 360, 600, 720, 900, 1200, 1500, 1800, 3000, 3600]   # register-resident table
+BIG = [4000, 4608, 5000, 6000, 6144, 8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
 
 
@@ -99,7 +100,7 @@ def test_fft_vs_truth_big(ctx, oracle, n):
 def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 2048).algorithm == "stockham_pow2"
     assert HipFft(ctx, 100).algorithm == "stockham_mixed_reg"
-    assert HipFft(ctx, 120).algorithm == "stockham_mixed"
+    assert HipFft(ctx, 126).algorithm == "stockham_mixed"
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
 
