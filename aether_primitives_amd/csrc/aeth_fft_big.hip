@@ -300,6 +300,9 @@ int fft_plan_bluestein(aeth_fft *plan)
 int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
     const size_t N = plan->len, M = plan->blu_m;
+    if (plan->blu_sub->algo == FFT_ALGO_POW2 && M <= 4096 && N * batch < 0x7fffffffull)
+        // the whole chirp-z chain in one launch; DFT+(x) = conj(DFT-(conj x)) by conjugating on the way in and out
+        return fmi_bluestein(plan->blu_sub, in, out, N, batch, plan->blu_chirp, plan->blu_filt, sign > 0 ? 1 : 0, scale);
     int rc = ensure_work(plan, M * batch);
     if (rc) return rc;
     aeth_ctx *ctx = plan->ctx;

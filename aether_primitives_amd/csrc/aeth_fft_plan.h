@@ -42,5 +42,8 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
 int fft_plan_bluestein(aeth_fft *plan);
 int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 void fft_plan_release_children(aeth_fft *plan);
+// aeth_fir.hip: chirp-z frames through the fused transform * filter * inverse kernel in one launch
+int fmi_bluestein(aeth_fft *sub, const float2 *in, float2 *out, size_t n, size_t batch, const float2 *chirp,
+                  const float2 *filt, int conj, float scale);
 
 }  // namespace aeth

@@ -49,6 +49,11 @@ struct FmiArgs {
     int hop, ov, nhist;
     float s_fwd, s_bwd;
     int dbg;              // tuning only (AETH_FIR_DBG): 4 = gather the twiddles instead of the per-lane table
+    // chirp-z (Bluestein) mode: a block is one frame of frame_n < N samples, multiplied by chirp[e] on the way in
+    // and on the way out, zero beyond frame_n; conj = transform with the other exponent sign
+    const cf *chirp = nullptr;
+    int frame_n = 0;      // valid samples per window (0: the whole window)
+    int conj = 0;
 };
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -75,7 +80,7 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
         if (win0 >= 0) {
             // wave-uniform window: buffer loads, the descriptor's range check zero-fills past the end
             long long left = a.n - win0;
-            int bytes = (int)(left < C::N ? left : C::N) * 8;
+            int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;
             auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
             for (int m = 0; m < C::P; m++)
@@ -90,11 +95,20 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
         // the loads need no per-element range logic, only the zeroing of the samples older than the history
         const long long first = (blk - (long long)(threadIdx.x / C::T)) * a.hop - a.ov;
         const long long last_end = first + (long long)(C::F - 1) * a.hop + C::N;
-        if (first >= 0 && last_end <= a.n && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
+        if (a.frame_n == C::N && first >= 0 && last_end <= a.n && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
 #pragma unroll
             for (int m = 0; m < C::P; m++) {
                 const cf v = a.in[win0 + tid + m * C::T];
                 x[m] = (tid + m * C::T >= a.ov - a.nhist) ? v : mk(0.f, 0.f);
+            }
+            return;
+        }
+        if (a.frame_n < C::N && a.ov == 0 && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
+            // chirp-z frames (hop = frame_n samples each, zero beyond): every frame of the group exists
+#pragma unroll
+            for (int m = 0; m < C::P; m++) {
+                const int e = tid + m * C::T;
+                x[m] = e < a.frame_n ? a.in[win0 + e] : mk(0.f, 0.f);
             }
             return;
         }
@@ -103,7 +117,7 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
     for (int m = 0; m < C::P; m++) {
         const long long gi = win0 + tid + m * C::T;
         cf v = mk(0.f, 0.f);
-        if (tid + m * C::T >= a.ov - a.nhist) {
+        if (tid + m * C::T >= a.ov - a.nhist && tid + m * C::T < a.frame_n) {
             if (gi >= 0) { if (gi < a.n) v = a.in[gi]; }
             else if (a.hist && gi >= -(long long)a.nhist) v = a.hist[a.nhist + gi];
         }
@@ -121,7 +135,7 @@ __device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a,
     const bool active = blk < a.nblocks;
     const long long win0 = active ? blk * a.hop - a.ov : 0;
     long long left = a.n - win0;
-    const int bytes = active ? (int)(left < C::N ? left : C::N) * 8 : 0;
+    const int bytes = active ? (int)(left < a.frame_n ? left : a.frame_n) * 8 : 0;
     auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
     for (int m = 0; m < C::P; m++)
@@ -135,7 +149,7 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
     const long long base = blk * a.hop - a.ov;              // output index of window element 0
     if constexpr (C::F == 1) {
         long long left = a.n - base;
-        int bytes = (int)(left < C::N ? left : C::N) * 8;   // stores past the end are dropped by the range check
+        int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;   // stores past the end (of the stream, of the frame) are dropped by the range check
         auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + base, 0, bytes, 0x00020000);
         const cf ss = mk(a.s_bwd, a.s_bwd);
         // no branch around the stores either: window elements in front of the valid part
@@ -152,13 +166,14 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
         for (int m = 0; m < C::P; m++) {
             const int e = tid + m * C::T;
             const long long o = base + e;
-            if (e >= a.ov && o < a.n) a.out[o] = SCALED ? cscale(w[m], a.s_bwd) : w[m];
+            if (e >= a.ov && o < a.n && e < a.frame_n) a.out[o] = SCALED ? cscale(w[m], a.s_bwd) : w[m];
         }
     }
 }
 
 // SCALED = false: both Scale factors are 1 (FIR: 1/N is folded into H)
-template <class C, bool SCALED, int MINW, bool NT>
+// BLU: chirp-z frames (see FmiArgs): the frame is multiplied by the chirp behind the load and in front of the store
+template <class C, bool SCALED, int MINW, bool NT, bool BLU>
 __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
 {
     __shared__ cf lds_all[C::LDS_TOTAL];
@@ -194,6 +209,17 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         // block is a function of exactly x[out0-(ntaps-1) .. out0+hop): shards of one stream
         // (history = ntaps-1 samples) then reproduce the unsharded run bit for bit
         if constexpr (C::F == 1) { if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f); }
+        if constexpr (BLU) {
+            // x[n] (conjugated for the other exponent sign) * chirp[n]; chirp is 0 beyond the frame (descriptor range)
+            auto cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.chirp), 0, a.frame_n * 8, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < C::P; m++) {
+                const cf ch = as_cf(__builtin_amdgcn_raw_buffer_load_b64(cr, (tid + m * C::T) * 8, 0, 0));
+                cf v = w[m];
+                if (a.conj) v.y = -v.y;
+                w[m] = cmul(v, ch);
+            }
+        }
         const long long gn = g + gridDim.x;
         if constexpr (C::F == 1) {
             // gn >= gridDim.x >= 1, so the window never starts before the stream: descriptor path
@@ -211,6 +237,16 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
 #pragma unroll
         for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);             // vec_mul (vecops.rs:99-112)
         fft_in_regs<C, -1, fft_next_par<C>(0)>(w, tw, lds, tid);   // vec_rifft: bwd (-j); two transforms leave the parity even
+        if constexpr (BLU) {
+            auto cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.chirp), 0, a.frame_n * 8, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < C::P; m++) {
+                const cf ch = as_cf(__builtin_amdgcn_raw_buffer_load_b64(cr, (tid + m * C::T) * 8, 0, 0));
+                cf v = cmul(w[m], ch);
+                if (a.conj) v.y = -v.y;
+                w[m] = v;
+            }
+        }
         store_block<C, SCALED, NT>(w, a, blk, tid);
     }
 }
@@ -228,10 +264,18 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     if (b.dbg & 4) b.twL = nullptr;
     const int g = aeth::tuning_int("AETH_FIR_GRID", 0);
     if (g > 0 && g < grid) grid = g;
-    if (aeth::streams_past_cache(2 * (size_t)a.n * sizeof(float2)))
-        hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true>), dim3(grid), dim3(C::WG), 0, stream, b);
-    else
-        hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false>), dim3(grid), dim3(C::WG), 0, stream, b);
+    if (b.frame_n == 0) b.frame_n = C::N;
+    const bool nt = aeth::streams_past_cache(2 * (size_t)a.n * sizeof(float2));
+    if constexpr (SCALED) {
+        if (b.chirp) {                                      // chirp-z frames always carry a scale factor
+            if (nt) hipLaunchKernelGGL((fmi_kernel<C, true, 1, true, true>), dim3(grid), dim3(C::WG), 0, stream, b);
+            else hipLaunchKernelGGL((fmi_kernel<C, true, 1, false, true>), dim3(grid), dim3(C::WG), 0, stream, b);
+            AETH_HIP(hipGetLastError());
+            return AETH_OK;
+        }
+    }
+    if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false>), dim3(grid), dim3(C::WG), 0, stream, b);
+    else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false>), dim3(grid), dim3(C::WG), 0, stream, b);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -240,7 +284,7 @@ int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a, hipStream_t st
 {
     if (!stream) stream = ctx->stream;
     aeth::DeviceGuard dev_guard(ctx->device);
-    const bool scaled = !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
+    const bool scaled = a.chirp != nullptr || !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
 #define AETH_BODY(NN)                                                            \
     return scaled ? launch_fmi<typename CfgFor<NN>::type, true>(ctx, a, stream)  \
                   : launch_fmi<typename CfgFor<NN>::type, false>(ctx, a, stream)
@@ -251,6 +295,26 @@ int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a, hipStream_t st
 bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
 
 }  // namespace
+
+namespace aeth {
+
+// Chirp-z transform of `batch` frames of n samples in ONE launch: x*chirp -> fwd_M -> *filt -> bwd_M -> *chirp,
+// zero-padded to M = sub->len in registers (aeth_fft_big.hip: fft_run_bluestein, M <= 4096).
+int fmi_bluestein(aeth_fft *sub, const float2 *in, float2 *out, size_t n, size_t batch, const float2 *chirp,
+                  const float2 *filt, int conj, float scale)
+{
+    FmiArgs a;
+    a.dbg = 0;
+    a.in = (const cf *)in; a.out = (cf *)out; a.hist = nullptr; a.Hf = (const cf *)filt;
+    a.twN = (const cf *)sub->tw_dev; a.twL = (const cf *)sub->tw_lane_dev;
+    a.n = (long long)(n * batch); a.nblocks = (long long)batch;
+    a.hop = (int)n; a.ov = 0; a.nhist = 0;
+    a.s_fwd = 1.0f; a.s_bwd = scale;
+    a.chirp = (const cf *)chirp; a.frame_n = (int)n; a.conj = conj;
+    return dispatch_fmi(sub->ctx, sub->len, a);
+}
+
+}  // namespace aeth
 
 extern "C" {
 
