@@ -660,6 +660,7 @@ int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sig
     case FFT_ALGO_POW2:  return dispatch_pow2(plan, in, out, batch, sign, scale);
     case FFT_ALGO_MIXED: return launch_mixed(plan, in, out, batch, sign, scale);
     case FFT_ALGO_REGMIX: return dispatch_regmix(plan, in, out, batch, sign, scale);
+    case FFT_ALGO_RAGGED: return fft_run_ragged(plan, in, out, batch, sign, scale);
     case FFT_ALGO_FOURSTEP: return fft_run_fourstep(plan, in, out, batch, sign, scale);
     case FFT_ALGO_BLUESTEIN: return fft_run_bluestein(plan, in, out, batch, sign, scale);
     default: return set_error(AETH_E_UNSUPPORTED, "no kernel path for length %zu", plan->len);
@@ -690,6 +691,9 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     } else if (is_pow2(len) && len <= 8192) {
         p->algo = aeth::FFT_ALGO_POW2;
         p->algo_name = "stockham_pow2";
+    } else if (aeth::fft_ragged_supported(len) && !aeth::tuning_int("AETH_FFT_NORAGGED", 0)) {
+        p->algo = aeth::FFT_ALGO_RAGGED;
+        p->algo_name = "stockham_mixed_ragged";
     } else if (regmix_supported(len) && !aeth::tuning_int("AETH_FFT_NOREGMIX", 0)) {
         p->algo = aeth::FFT_ALGO_REGMIX;
         p->algo_name = "stockham_mixed_reg";
@@ -709,6 +713,7 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_POW2) rc = plan_pow2(p);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_MIXED) rc = plan_mixed(p);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_REGMIX) rc = plan_regmix(p);
+    if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_RAGGED) rc = aeth::fft_plan_ragged(p);
     if (rc == AETH_OK) rc = aeth::fft_ensure_tmp(p, 2 * len * max_batch);
     if (rc == AETH_OK) {
         hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * len * sizeof(float2), hipHostMallocDefault);

@@ -576,71 +576,36 @@ template <> struct CfgFor<8192> { using type = Cfg<8192, 16, 16, 16, 8, 4>; };
     default: DEFAULT;                                                                  \
     }
 
-// ---- register-resident transforms of lengths with factors 3 and 5 -----------------------------
-// Same engine, radices 3/5/6/10/12/15/20/24/25 in registers; T = N/P is no power of two, so the workgroup
-// size is given and a few lanes idle.  Only lengths whose radices all divide P qualify (the rest goes through
-// the LDS ping-pong kernel): the table below is the set of such lengths worth a kernel instantiation.
+// ---- register-resident transforms of the lengths 2^a * 3^b on 12- and 24-point lanes ----------
+// Same engine, radices 3/8/12/24 in registers; T = N/P is no power of two, so the workgroup size is given and a
+// few lanes idle.  Only lengths whose radices all divide P qualify.  (Lengths with a factor 5 run through
+// aeth_fft_ragged.h, whose passes do not share a lane shape; it measured faster on every one of them.  The
+// radix 5/6/10/15/20/25 butterflies above are its building blocks.)
 template <int N> struct CfgMixFor;
 template <> struct CfgMixFor<96> { using type = Cfg<96, 24, 24, 4, 1, 1, 64>; };
-template <> struct CfgMixFor<100> { using type = Cfg<100, 10, 10, 10, 1, 1, 256>; };
 template <> struct CfgMixFor<144> { using type = Cfg<144, 12, 12, 12, 1, 1, 192>; };
 template <> struct CfgMixFor<192> { using type = Cfg<192, 24, 24, 8, 1, 1, 64>; };
-template <> struct CfgMixFor<200> { using type = Cfg<200, 10, 10, 10, 2, 1, 320>; };
 template <> struct CfgMixFor<288> { using type = Cfg<288, 24, 24, 12, 1, 1, 192>; };
 template <> struct CfgMixFor<384> { using type = Cfg<384, 24, 24, 8, 2, 1, 64>; };
-template <> struct CfgMixFor<400> { using type = Cfg<400, 10, 10, 10, 2, 2, 320>; };
-template <> struct CfgMixFor<500> { using type = Cfg<500, 10, 10, 10, 5, 1, 256>; };
 template <> struct CfgMixFor<576> { using type = Cfg<576, 24, 24, 24, 1, 1, 192>; };
-template <> struct CfgMixFor<625> { using type = Cfg<625, 25, 25, 25, 1, 1, 128>; };
 template <> struct CfgMixFor<768> { using type = Cfg<768, 24, 24, 8, 4, 1, 64>; };
-template <> struct CfgMixFor<800> { using type = Cfg<800, 20, 20, 20, 2, 1, 320>; };
-template <> struct CfgMixFor<1000> { using type = Cfg<1000, 10, 10, 10, 10, 1, 512>; };
 template <> struct CfgMixFor<1152> { using type = Cfg<1152, 24, 24, 24, 2, 1, 192>; };
 template <> struct CfgMixFor<1536> { using type = Cfg<1536, 24, 24, 8, 8, 1, 64>; };
-template <> struct CfgMixFor<1600> { using type = Cfg<1600, 20, 20, 20, 4, 1, 320>; };
-template <> struct CfgMixFor<2000> { using type = Cfg<2000, 20, 20, 20, 5, 1, 320>; };
 template <> struct CfgMixFor<2304> { using type = Cfg<2304, 24, 24, 24, 4, 1, 192>; };
-template <> struct CfgMixFor<2500> { using type = Cfg<2500, 10, 10, 10, 5, 5, 256>; };
-template <> struct CfgMixFor<3072> { using type = Cfg<3072, 24, 24, 8, 8, 2, 128>; };
-template <> struct CfgMixFor<4000> { using type = Cfg<4000, 20, 20, 20, 10, 1, 448>; };
 template <> struct CfgMixFor<4608> { using type = Cfg<4608, 24, 24, 24, 8, 1, 192>; };
-template <> struct CfgMixFor<5000> { using type = Cfg<5000, 10, 10, 10, 10, 5, 512>; };
-template <> struct CfgMixFor<6144> { using type = Cfg<6144, 24, 24, 8, 8, 4, 256>; };
-
-template <> struct CfgMixFor<120> { using type = Cfg<120, 30, 10, 6, 2, 1, 64>; };
-template <> struct CfgMixFor<600> { using type = Cfg<600, 30, 10, 10, 6, 1, 64>; };
-template <> struct CfgMixFor<1200> { using type = Cfg<1200, 30, 10, 10, 6, 2, 128>; };
-template <> struct CfgMixFor<3000> { using type = Cfg<3000, 30, 15, 10, 10, 2, 128>; };
-template <> struct CfgMixFor<240> { using type = Cfg<240, 30, 10, 6, 2, 2, 64>; };
-template <> struct CfgMixFor<300> { using type = Cfg<300, 30, 15, 10, 2, 1, 64>; };
-template <> struct CfgMixFor<360> { using type = Cfg<360, 30, 10, 6, 6, 1, 64>; };
-template <> struct CfgMixFor<720> { using type = Cfg<720, 30, 10, 6, 6, 2, 64>; };
-template <> struct CfgMixFor<900> { using type = Cfg<900, 30, 15, 10, 6, 1, 64>; };
-template <> struct CfgMixFor<1500> { using type = Cfg<1500, 30, 15, 10, 10, 1, 256>; };
-template <> struct CfgMixFor<1800> { using type = Cfg<1800, 30, 15, 10, 6, 2, 128>; };
-template <> struct CfgMixFor<3600> { using type = Cfg<3600, 30, 10, 10, 6, 6, 128>; };
-template <> struct CfgMixFor<6000> { using type = Cfg<6000, 30, 10, 10, 10, 6, 256>; };
 
 #define AETH_REGMIX_SWITCH(len, BODY, DEFAULT)                                          \
     switch (len) {                                                                     \
-    case 96: BODY(96); case 100: BODY(100); case 144: BODY(144); case 192: BODY(192);  \
-    case 200: BODY(200); case 288: BODY(288); case 384: BODY(384); case 400: BODY(400);\
-    case 500: BODY(500); case 576: BODY(576); case 625: BODY(625); case 768: BODY(768);\
-    case 800: BODY(800); case 1000: BODY(1000); case 1152: BODY(1152); case 1536: BODY(1536);\
-    case 1600: BODY(1600); case 2000: BODY(2000); case 2304: BODY(2304); case 2500: BODY(2500);\
-    case 3072: BODY(3072); case 4000: BODY(4000); case 4608: BODY(4608); case 5000: BODY(5000);\
-    case 6144: BODY(6144);                                                             \
-    case 120: BODY(120); case 600: BODY(600); case 1200: BODY(1200); case 3000: BODY(3000);  \
-    case 240: BODY(240); case 300: BODY(300); case 360: BODY(360); case 720: BODY(720); case 900: BODY(900); \
-    case 1500: BODY(1500); case 1800: BODY(1800); case 3600: BODY(3600); case 6000: BODY(6000); \
+    case 96: BODY(96); case 144: BODY(144); case 192: BODY(192);                       \
+    case 288: BODY(288); case 384: BODY(384); case 576: BODY(576);                     \
+    case 768: BODY(768); case 1152: BODY(1152); case 1536: BODY(1536);                 \
+    case 2304: BODY(2304); case 4608: BODY(4608);                                      \
     default: DEFAULT;                                                                  \
     }
 constexpr bool regmix_supported(size_t len)
 {
     switch (len) {
-    case 96: case 100: case 144: case 192: case 200: case 288: case 384: case 400: case 500: case 576: case 625: case 768: case 800: case 1000: case 1152: case 1536: case 1600: case 2000: case 2304: case 2500: case 3072: case 4000: case 4608: case 5000: case 6144:
-    case 120: case 600: case 1200: case 3000: case 240: case 300: case 360: case 720: case 900: case 1500: case 1800:
-    case 3600: case 6000:
+    case 96: case 144: case 192: case 288: case 384: case 576: case 768: case 1152: case 1536: case 2304: case 4608:
         return true;
     default: return false;
     }

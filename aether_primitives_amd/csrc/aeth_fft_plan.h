@@ -32,7 +32,7 @@ struct aeth_fft {
 
 namespace aeth {
 
-enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_REGMIX = 5 };
+enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_REGMIX = 5, FFT_ALGO_RAGGED = 6 };
 
 int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 int fft_ensure_tmp(aeth_fft *plan, size_t elems);
@@ -42,6 +42,10 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
 int fft_plan_bluestein(aeth_fft *plan);
 int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 void fft_plan_release_children(aeth_fft *plan);
+// aeth_fft_ragged.hip: register-resident transforms of the 2*3*5-smooth table lengths
+bool fft_ragged_supported(size_t len);
+int fft_plan_ragged(aeth_fft *plan);
+int fft_run_ragged(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 // aeth_fir.hip: chirp-z frames through the fused transform * filter * inverse kernel in one launch
 int fmi_bluestein(aeth_fft *sub, const float2 *in, float2 *out, size_t n, size_t batch, const float2 *chirp,
                   const float2 *filt, int conj, float scale);

@@ -22,8 +22,9 @@ TOL_DB = -120.0
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 MIXED = [1, 3, 5, 6, 7, 9, 10, 12, 15, 20, 25, 49, 60, 61, 100, 120, 210, 1000, 1155, 3125, 4095,
          96, 144, 192, 200, 288, 384, 400, 500, 576, 625, 768, 800, 1152, 1536, 1600, 2000, 2304, 2500, 3072,
-         240, 300, 360, 600, 720, 900, 1200, 1500, 1800, 3000, 3600]   # register-resident table
-BIG = [4000, 4608, 5000, 6000, 6144, 8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
+         240, 300, 360, 600, 720, 900, 1200, 1500, 1800, 3000, 3600,   # register-resident tables
+         480, 640, 960, 1080, 1280, 1440, 1920, 2160, 2400, 2560, 2880, 3840]
+BIG = [4000, 4320, 4608, 4800, 5000, 5120, 5400, 5760, 6000, 6144, 7200, 8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
 
 
@@ -66,7 +67,7 @@ def test_reference_roundtrip_100(ctx):
     c.vec_fft(Scale.SN).vec_ifft(Scale.SN)
     ap.assert_evm(c.to_host(), v)
     c = ctx.vec(v); f = HipFft(ctx, 100)
-    assert f.algorithm in ("stockham_mixed", "stockham_mixed_reg")
+    assert f.algorithm in ("stockham_mixed", "stockham_mixed_reg", "stockham_mixed_ragged")
     c.vec_rfft(f, Scale.SN).vec_rifft(f, Scale.SN)
     ap.assert_evm(c.to_host(), v)
     h = v.copy(); ap.HostVec(ctx, h).vec_rfft(f, Scale.SN).vec_rifft(f, Scale.SN)
@@ -97,9 +98,28 @@ def test_fft_vs_truth_big(ctx, oracle, n):
         assert bits_equal(d.to_host(), out.to_host())
 
 
+@pytest.mark.parametrize("n", [100, 120, 480, 1000, 3600, 6000, 7200])
+def test_ragged_streaming_batch_matches_small_batches(ctx, n):
+    """Batches beyond the cache take the non-temporal instantiation and the persistent grid wraps several times;
+    the bits must be those of the same frames transformed a handful at a time."""
+    f = HipFft(ctx, n)
+    assert f.algorithm == "stockham_mixed_ragged"
+    batch = (9 << 20) // n + 3                                   # > 128 MiB of traffic, ragged last group
+    x = rand_c64(77 + n, n * batch)
+    big = ctx.empty(n * batch)
+    f.exec(ctx.vec(x), big, +1)
+    got = big.to_host().reshape(batch, n)
+    for lo in (0, batch // 2 - 2, batch - 5):
+        part = x.reshape(batch, n)[lo:lo + 5].reshape(-1)
+        out = ctx.empty(5 * n)
+        f.exec(ctx.vec(part), out, +1)
+        assert bits_equal(out.to_host().reshape(5, n), got[lo:lo + 5]), (n, lo)
+
+
 def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 2048).algorithm == "stockham_pow2"
-    assert HipFft(ctx, 100).algorithm == "stockham_mixed_reg"
+    assert HipFft(ctx, 100).algorithm == "stockham_mixed_ragged"
+    assert HipFft(ctx, 96).algorithm == "stockham_mixed_reg"
     assert HipFft(ctx, 126).algorithm == "stockham_mixed"
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
