@@ -2,11 +2,14 @@
 // (src/fft.rs:48-77) / `Cfft` (src/fft.rs:134-235).
 //
 // Kernel paths (chosen per length at plan time):
-//   stockham_pow2   N = 2..4096, power of two: register radix-16/8/4 Stockham, one
+//   stockham_pow2   N = 2..8192, power of two: register radix-16/8/4 Stockham, one
 //                   frame per T = N/P lanes, data exchanged through LDS between
 //                   passes, twiddles held in registers across a persistent loop over
 //                   frames.  16 B/sample of HBM traffic (8 R + 8 W), scale fused.
-//   stockham_mixed  N <= 4096 with prime factors <= 61: one workgroup per frame,
+//   stockham_mixed_ragged  every other N = 2^a 3^b 5^c up to 7500: the same idea with
+//                   passes that do not share a lane shape (aeth_fft_ragged.h/.hip),
+//                   one measured decomposition per length.
+//   stockham_mixed  other N <= 8192 with prime factors <= 61: one workgroup per frame,
 //                   LDS ping-pong, radix 2/3/4/5/7/8 butterflies (3 and 5 in
 //                   sum/difference form so that constant inputs give exactly-zero
 //                   bins, as the reference's own FFT tests expect: fft.rs:93-104,
@@ -220,49 +223,6 @@ int plan_pow2(aeth_fft *plan)
 {
 #define AETH_BODY(NN) return build_lane_table<typename CfgFor<NN>::type>(plan)
     AETH_POW2_SWITCH_XL(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
-#undef AETH_BODY
-}
-
-// lengths with factors 3 / 5 whose radices divide P: the same kernels, CfgMixFor<N>
-template <class C>
-int launch_regmix(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
-{
-    const aeth_ctx *ctx = plan->ctx;
-    const bool nt = aeth::streams_past_cache(2 * batch * (size_t)C::N * sizeof(float2));
-    if constexpr (C::F == 1 && C::IDLE == 0 && C::P <= 16) {
-        // a whole number of waves per frame and registers to spare: the descriptor / prefetch pipeline of the power-of-two kernels
-        size_t cap2 = (size_t)ctx->num_cus * (512 / C::WG);
-        int grid2 = (int)(batch < cap2 ? batch : cap2);
-        if (grid2 < 1) grid2 = 1;
-#define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
-        if (sign > 0) { if (nt) AETH_FFT_STREAM(+1, true); else AETH_FFT_STREAM(+1, false); }
-        else          { if (nt) AETH_FFT_STREAM(-1, true); else AETH_FFT_STREAM(-1, false); }
-#undef AETH_FFT_STREAM
-    } else {
-        const size_t ngroups = (batch + C::F - 1) / C::F;
-        const size_t cap = (size_t)ctx->num_cus * (2048 / C::WG);     // fill the CU with waves: the loop has no prefetch stage
-        int grid = (int)(ngroups < cap ? ngroups : cap);
-        if (grid < 1) grid = 1;
-#define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
-        if (sign > 0) { if (nt) AETH_FFT_PLAIN(+1, true); else AETH_FFT_PLAIN(+1, false); }
-        else          { if (nt) AETH_FFT_PLAIN(-1, true); else AETH_FFT_PLAIN(-1, false); }
-#undef AETH_FFT_PLAIN
-    }
-    AETH_HIP(hipGetLastError());
-    return AETH_OK;
-}
-
-int dispatch_regmix(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
-{
-#define AETH_BODY(NN) return launch_regmix<typename CfgMixFor<NN>::type>(plan, in, out, batch, sign, scale)
-    AETH_REGMIX_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_mixed_reg: length %zu", plan->len))
-#undef AETH_BODY
-}
-
-int plan_regmix(aeth_fft *plan)
-{
-#define AETH_BODY(NN) return build_lane_table<typename CfgMixFor<NN>::type>(plan)
-    AETH_REGMIX_SWITCH(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_mixed_reg: length %zu", plan->len))
 #undef AETH_BODY
 }
 
@@ -659,7 +619,6 @@ int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sig
     switch (plan->algo) {
     case FFT_ALGO_POW2:  return dispatch_pow2(plan, in, out, batch, sign, scale);
     case FFT_ALGO_MIXED: return launch_mixed(plan, in, out, batch, sign, scale);
-    case FFT_ALGO_REGMIX: return dispatch_regmix(plan, in, out, batch, sign, scale);
     case FFT_ALGO_RAGGED: return fft_run_ragged(plan, in, out, batch, sign, scale);
     case FFT_ALGO_FOURSTEP: return fft_run_fourstep(plan, in, out, batch, sign, scale);
     case FFT_ALGO_BLUESTEIN: return fft_run_bluestein(plan, in, out, batch, sign, scale);
@@ -694,9 +653,6 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     } else if (aeth::fft_ragged_supported(len) && !aeth::tuning_int("AETH_FFT_NORAGGED", 0)) {
         p->algo = aeth::FFT_ALGO_RAGGED;
         p->algo_name = "stockham_mixed_ragged";
-    } else if (regmix_supported(len) && !aeth::tuning_int("AETH_FFT_NOREGMIX", 0)) {
-        p->algo = aeth::FFT_ALGO_REGMIX;
-        p->algo_name = "stockham_mixed_reg";
     } else if (len <= 8192 && factorize_mixed(len, p->factors)) {      // two LDS images of the frame: 128 KiB at most
         p->algo = aeth::FFT_ALGO_MIXED;
         p->algo_name = "stockham_mixed";
@@ -712,7 +668,6 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     if (rc == AETH_OK) rc = make_twiddles(ctx, len, &p->tw_dev);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_POW2) rc = plan_pow2(p);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_MIXED) rc = plan_mixed(p);
-    if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_REGMIX) rc = plan_regmix(p);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_RAGGED) rc = aeth::fft_plan_ragged(p);
     if (rc == AETH_OK) rc = aeth::fft_ensure_tmp(p, 2 * len * max_batch);
     if (rc == AETH_OK) {

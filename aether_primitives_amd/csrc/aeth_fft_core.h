@@ -368,6 +368,11 @@ template <int S> struct Bfly<15, S> : BflyC<5, 3, S> {};
 template <int S> struct Bfly<20, S> : BflyC<5, 4, S> {};
 template <int S> struct Bfly<24, S> : BflyC<8, 3, S> {};
 template <int S> struct Bfly<25, S> : BflyC<5, 5, S> {};
+template <int S> struct Bfly<9, S>  : BflyC<3, 3, S> {};
+template <int S> struct Bfly<18, S> : BflyC<6, 3, S> {};
+template <int S> struct Bfly<27, S> : BflyC<9, 3, S> {};
+template <int S> struct Bfly<30, S> : BflyC<6, 5, S> {};
+template <int S> struct Bfly<32, S> : BflyC<8, 4, S> {};
 
 // ---- compile-time description of one transform size ---------------------------
 // WG_ = 0: the power-of-two rule (T lanes, at least 64).  WG_ > 0: that many lanes; F = WG / T frames, the
@@ -575,41 +580,6 @@ template <> struct CfgFor<8192> { using type = Cfg<8192, 16, 16, 16, 8, 4>; };
     case 4096: BODY(4096);                                                             \
     default: DEFAULT;                                                                  \
     }
-
-// ---- register-resident transforms of the lengths 2^a * 3^b on 12- and 24-point lanes ----------
-// Same engine, radices 3/8/12/24 in registers; T = N/P is no power of two, so the workgroup size is given and a
-// few lanes idle.  Only lengths whose radices all divide P qualify.  (Lengths with a factor 5 run through
-// aeth_fft_ragged.h, whose passes do not share a lane shape; it measured faster on every one of them.  The
-// radix 5/6/10/15/20/25 butterflies above are its building blocks.)
-template <int N> struct CfgMixFor;
-template <> struct CfgMixFor<96> { using type = Cfg<96, 24, 24, 4, 1, 1, 64>; };
-template <> struct CfgMixFor<144> { using type = Cfg<144, 12, 12, 12, 1, 1, 192>; };
-template <> struct CfgMixFor<192> { using type = Cfg<192, 24, 24, 8, 1, 1, 64>; };
-template <> struct CfgMixFor<288> { using type = Cfg<288, 24, 24, 12, 1, 1, 192>; };
-template <> struct CfgMixFor<384> { using type = Cfg<384, 24, 24, 8, 2, 1, 64>; };
-template <> struct CfgMixFor<576> { using type = Cfg<576, 24, 24, 24, 1, 1, 192>; };
-template <> struct CfgMixFor<768> { using type = Cfg<768, 24, 24, 8, 4, 1, 64>; };
-template <> struct CfgMixFor<1152> { using type = Cfg<1152, 24, 24, 24, 2, 1, 192>; };
-template <> struct CfgMixFor<1536> { using type = Cfg<1536, 24, 24, 8, 8, 1, 64>; };
-template <> struct CfgMixFor<2304> { using type = Cfg<2304, 24, 24, 24, 4, 1, 192>; };
-template <> struct CfgMixFor<4608> { using type = Cfg<4608, 24, 24, 24, 8, 1, 192>; };
-
-#define AETH_REGMIX_SWITCH(len, BODY, DEFAULT)                                          \
-    switch (len) {                                                                     \
-    case 96: BODY(96); case 144: BODY(144); case 192: BODY(192);                       \
-    case 288: BODY(288); case 384: BODY(384); case 576: BODY(576);                     \
-    case 768: BODY(768); case 1152: BODY(1152); case 1536: BODY(1536);                 \
-    case 2304: BODY(2304); case 4608: BODY(4608);                                      \
-    default: DEFAULT;                                                                  \
-    }
-constexpr bool regmix_supported(size_t len)
-{
-    switch (len) {
-    case 96: case 144: case 192: case 288: case 384: case 576: case 768: case 1152: case 1536: case 2304: case 4608:
-        return true;
-    default: return false;
-    }
-}
 
 // the same plus the lengths only the plain transform kernels are built for
 #define AETH_POW2_SWITCH_XL(len, BODY, DEFAULT)                                         \

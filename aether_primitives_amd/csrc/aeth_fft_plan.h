@@ -32,7 +32,7 @@ struct aeth_fft {
 
 namespace aeth {
 
-enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_REGMIX = 5, FFT_ALGO_RAGGED = 6 };
+enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_RAGGED = 5 };
 
 int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 int fft_ensure_tmp(aeth_fft *plan, size_t elems);
@@ -42,7 +42,12 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
 int fft_plan_bluestein(aeth_fft *plan);
 int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 void fft_plan_release_children(aeth_fft *plan);
-// aeth_fft_ragged.hip: register-resident transforms of the 2*3*5-smooth table lengths
+// aeth_fft_ragged.hip: register-resident transforms of the 5-smooth lengths (table compiled in four slices)
+enum { kRaggedNotHere = 1 };
+int fft_ragged_slice0(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+int fft_ragged_slice1(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+int fft_ragged_slice2(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+int fft_ragged_slice3(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 bool fft_ragged_supported(size_t len);
 int fft_plan_ragged(aeth_fft *plan);
 int fft_run_ragged(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);

@@ -27,7 +27,7 @@ namespace fftk {
 #define AETH_RAGGED_DB_LIMIT (40 * 1024)   /* two exchange images up to this many bytes per workgroup */
 #endif
 
-template <int N_, int T_, int WG_, int R0_, int R1_, int R2_ = 1, int R3_ = 1, int STAGE_ = -1>
+template <int N_, int T_, int WG_, int R0_, int R1_ = 1, int R2_ = 1, int R3_ = 1, int STAGE_ = -1>
 struct RCfg {
     static constexpr int N = N_, T = T_, WG = WG_;
     static constexpr int F = WG / T;                 // frames per workgroup
@@ -127,8 +127,13 @@ __device__ __forceinline__ void ragged_pass(const cf (&tw)[C::TW], const cf *rd,
 }
 
 // NT: frames are streamed with the non-temporal hint (batches beyond the cache; aeth_internal.h)
+// Workgroups of 256 lanes and more are held to two waves per SIMD (256 registers): past that one workgroup has
+// the CU to itself and every barrier stalls it (N = 6000: 151 -> 123 us).  Smaller workgroups keep their registers:
+// several of them share a CU at one wave per SIMD, and spilling costs more than that (N = 480: 100 -> 148 us).
+template <class C> constexpr int ragged_min_waves() { return C::WG >= 256 ? 2 : 1; }
+
 template <class C, int S, bool NT>
-__global__ __launch_bounds__(C::WG) void fft_ragged_kernel(const cf *in, cf *out, const cf *__restrict__ twL,
+__global__ __launch_bounds__(C::WG, ragged_min_waves<C>()) void fft_ragged_kernel(const cf *in, cf *out, const cf *__restrict__ twL,
                                                             size_t batch, float scale)
 {
     __shared__ cf lds_all[C::LDS_TOTAL];

@@ -20,11 +20,11 @@ KAT = load_kat()
 TOL_DB = -120.0
 
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
-MIXED = [1, 3, 5, 6, 7, 9, 10, 12, 15, 20, 25, 49, 60, 61, 100, 120, 210, 1000, 1155, 3125, 4095,
-         96, 144, 192, 200, 288, 384, 400, 500, 576, 625, 768, 800, 1152, 1536, 1600, 2000, 2304, 2500, 3072,
-         240, 300, 360, 600, 720, 900, 1200, 1500, 1800, 3000, 3600,   # register-resident tables
-         480, 640, 960, 1080, 1280, 1440, 1920, 2160, 2400, 2560, 2880, 3840]
-BIG = [4000, 4320, 4608, 4800, 5000, 5120, 5400, 5760, 6000, 6144, 7200, 8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
+# every length 2^a 3^b 5^c below 7500 that is no power of two: the ragged register-resident table
+SMOOTH = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(9) for c in range(6)
+                 if 3 <= 2 ** a * 3 ** b * 5 ** c <= 7500} - {2 ** k for k in range(14)})
+MIXED = [1, 7, 14, 49, 61, 126, 210, 1155, 2401, 4095, 7680, 7776]           # LDS ping-pong kernel
+BIG = [8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
 
 
@@ -75,15 +75,20 @@ def test_reference_roundtrip_100(ctx):
 
 
 # ---- parity on random spectra ------------------------------------------------------
-@pytest.mark.parametrize("n", POW2 + MIXED)
+@pytest.mark.parametrize("n", POW2 + MIXED + SMOOTH)
 def test_fft_vs_truth_small(ctx, oracle, n):
     f = HipFft(ctx, n)
     assert f.len() == n
+    if n in SMOOTH:
+        assert f.algorithm == "stockham_mixed_ragged"
     for sign, batch in ((+1, 1), (-1, 1), (+1, 7), (-1, 130)):
         x = rand_c64(1000 * n + batch + sign, n * batch)
         out = ctx.empty(n * batch)
         f.exec(ctx.vec(x), out, sign)
         _check(oracle, out.to_host(), x, n, sign)
+        if batch == 7:
+            d = ctx.vec(x); f.exec(d, d, sign)                   # in place
+            assert bits_equal(d.to_host(), out.to_host())
 
 
 @pytest.mark.parametrize("n", BIG + ODD)
@@ -98,7 +103,7 @@ def test_fft_vs_truth_big(ctx, oracle, n):
         assert bits_equal(d.to_host(), out.to_host())
 
 
-@pytest.mark.parametrize("n", [100, 120, 480, 1000, 3600, 6000, 7200])
+@pytest.mark.parametrize("n", [3, 12, 25, 100, 120, 480, 1000, 3125, 3600, 6000, 7500])
 def test_ragged_streaming_batch_matches_small_batches(ctx, n):
     """Batches beyond the cache take the non-temporal instantiation and the persistent grid wraps several times;
     the bits must be those of the same frames transformed a handful at a time."""
@@ -119,7 +124,6 @@ def test_ragged_streaming_batch_matches_small_batches(ctx, n):
 def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 2048).algorithm == "stockham_pow2"
     assert HipFft(ctx, 100).algorithm == "stockham_mixed_ragged"
-    assert HipFft(ctx, 96).algorithm == "stockham_mixed_reg"
     assert HipFft(ctx, 126).algorithm == "stockham_mixed"
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
