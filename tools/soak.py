@@ -13,11 +13,10 @@ from helpers import rand_c64, bits_equal
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = ap.Context(0)
-lengths = [2 ** k for k in range(1, 17)] + [3, 5, 6, 7, 12, 15, 20, 60, 100, 120, 200, 360, 500, 1000, 1200, 1536, 3000, 3072,
-                                            5000, 6000, 8000, 17, 67, 127, 257, 1009, 4099, 6561, 2401,
-                                            96, 144, 192, 240, 288, 300, 384, 400, 576, 600, 625, 720, 768, 800, 900, 1152, 1500, 1600,
-                                            1800, 2000, 2304, 2500, 3600, 4000, 4608, 6144, 134, 509, 2039, 960, 2400,
-                                            480, 640, 1080, 1280, 1440, 1920, 2160, 2560, 2880, 3840, 4320, 4800, 5120, 5400, 5760, 7200]
+smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(9) for c in range(6)
+                 if 3 <= 2 ** a * 3 ** b * 5 ** c <= 7500} - {2 ** k for k in range(14)})      # the ragged table
+lengths = [2 ** k for k in range(1, 17)] + smooth + [7, 14, 17, 49, 67, 126, 127, 134, 257, 509, 1009, 2039, 2401, 4099,
+                                                     7680, 7776, 8000]
 plans, firs = {}, {}
 t0 = last = time.time(); it = 0; worst = -400.0
 while time.time() - t0 < secs:
