@@ -27,7 +27,9 @@ namespace fftk {
 #define AETH_RAGGED_DB_LIMIT (40 * 1024)   /* two exchange images up to this many bytes per workgroup */
 #endif
 
-template <int N_, int T_, int WG_, int R0_, int R1_ = 1, int R2_ = 1, int R3_ = 1, int STAGE_ = -1>
+// PAD_: one pad slot per 2^PAD_ elements of the exchange image (4 as in aeth_fft_core.h; 0: none -- the largest
+// frames trade bank conflicts for a third workgroup per CU)
+template <int N_, int T_, int WG_, int PAD_, int R0_, int R1_ = 1, int R2_ = 1, int R3_ = 1, int STAGE_ = -1>
 struct RCfg {
     static constexpr int N = N_, T = T_, WG = WG_;
     static constexpr int F = WG / T;                 // frames per workgroup
@@ -50,7 +52,8 @@ struct RCfg {
         return o;
     }
     static constexpr int TW = twoff(NPASS) > 0 ? twoff(NPASS) : 1;
-    static constexpr int FRAME = N + N / 16;          // padded LDS image of one frame (lidx)
+    static constexpr int FRAME = PAD_ > 0 ? N + (N >> PAD_) : N;          // padded LDS image of one frame
+    static __device__ __forceinline__ int at(int e) { return PAD_ > 0 ? e + (e >> PAD_) : e; }
     static constexpr int IMAGE = (NPASS > 1) ? FRAME * F : 0;
     static constexpr bool DB = (NPASS > 1) && (2 * IMAGE * 8 <= AETH_RAGGED_DB_LIMIT);
     // frames whose first or last pass touches memory in short rows go through an LDS copy of the group
@@ -94,7 +97,7 @@ __device__ __forceinline__ void ragged_pass(const cf (&tw)[C::TW], const cf *rd,
         for (int r = 0; r < R; r++) {
             if constexpr (from_mem) x[b][r] = act ? aeth::nt_load<NT>(rd + i + r * M) : mk(0.f, 0.f);
             else if constexpr (first) x[b][r] = act ? rd[i + r * M] : mk(0.f, 0.f);          // staged copy: unpadded
-            else x[b][r] = act ? rd[lidx(i + r * M)] : mk(0.f, 0.f);
+            else x[b][r] = act ? rd[C::at(i + r * M)] : mk(0.f, 0.f);
         }
     }
     // one exchange image: everybody has read it before anybody overwrites it
@@ -120,7 +123,7 @@ __device__ __forceinline__ void ragged_pass(const cf (&tw)[C::TW], const cf *rd,
                 const int k = i % p;
                 const int j = (i - k) * R + k;
 #pragma unroll
-                for (int r = 0; r < R; r++) wr[lidx(j + r * p)] = u[r];
+                for (int r = 0; r < R; r++) wr[C::at(j + r * p)] = u[r];
             }
         }
     }

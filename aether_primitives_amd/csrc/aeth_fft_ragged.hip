@@ -44,9 +44,9 @@ int build_ragged_table(aeth_fft *plan)
 }  // namespace
 
 // table rows of this slice become switch cases, the other slices' rows vanish
-#define AETH_RAGGED_ROW(N, T, WG, LANES, ...)                                                           \
+#define AETH_RAGGED_ROW(N, T, WG, LANES, PAD, ...)                                                           \
     case N: {                                                                                           \
-        using C = RCfg<N, T, WG, __VA_ARGS__>;                                                          \
+        using C = RCfg<N, T, WG, PAD, __VA_ARGS__>;                                                          \
         return in ? launch_ragged<C, LANES>(plan, in, out, batch, sign, scale) : build_ragged_table<C>(plan); \
     }
 #define AETH_RAGGED_SKIP(...)

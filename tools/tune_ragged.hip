@@ -19,7 +19,7 @@ static size_t g_total = (size_t)32 << 20;
 static int g_cus = 256;
 
 template <class C>
-void run(const char *radices, bool first)
+void run(const char *radices, bool first, int pad)
 {
     const size_t batch = g_total / C::N;
     std::vector<float2> tw(C::N);
@@ -64,15 +64,16 @@ void run(const char *radices, bool first)
             }
             err = 10 * log10(num / den + 1e-30);
         }
-        printf("N=%5d T=%4d WG=%4d F=%2d idle=%3d radices=%-12s staged=%d db=%d lds=%6d grid=%5d  %7.1f us  %5.2f TB/s  diff %.0f dB\n",
-               C::N, C::T, C::WG, C::F, C::IDLE, radices, (int)C::STAGED, (int)C::DB, C::LDS_TOTAL * 8, grid, us,
+        printf("N=%5d T=%4d WG=%4d F=%2d idle=%3d radices=%-12s pad=%d staged=%d db=%d lds=%6d grid=%5d  %7.1f us  %5.2f TB/s  diff %.0f dB\n",
+               C::N, C::T, C::WG, C::F, C::IDLE, radices, pad, (int)C::STAGED, (int)C::DB, C::LDS_TOTAL * 8, grid, us,
                16.0 * batch * C::N / us / 1e6, err);
         fflush(stdout);
     }
     CK(hipFree(twN)); CK(hipFree(twL));
 }
 
-#define CAND(first, N, T, WG, ...) run<RCfg<N, T, WG, __VA_ARGS__>>(#__VA_ARGS__, first)
+#define CAND(first, N, T, WG, ...) run<RCfg<N, T, WG, 4, __VA_ARGS__>>(#__VA_ARGS__, first, 4)
+#define CANDP(first, N, T, WG, PAD, ...) run<RCfg<N, T, WG, PAD, __VA_ARGS__>>(#__VA_ARGS__, first, PAD)
 
 int main(int argc, char **argv)
 {
