@@ -555,6 +555,27 @@ bool factorize_mixed(size_t n, std::vector<int> &fac)
     return n == 1 && fac.size() <= (size_t)kMaxFactors;
 }
 
+// len = n1 * n2, both factors at most 8192 and served by a single-workgroup kernel; the pair nearest the square
+// root whose factors are both register-resident (power of two or in the ragged table), else the nearest pair the
+// LDS mixed-radix kernel can do.
+bool split_fourstep_mixed(size_t len, size_t *n1, size_t *n2)
+{
+    size_t root = 1;
+    while ((root + 1) * (root + 1) <= len) root++;
+    size_t fb1 = 0, fb2 = 0;
+    std::vector<int> fac;
+    for (size_t a = root; a >= 2; a--) {
+        if (len % a) continue;
+        const size_t b = len / a;
+        if (b > 8192) break;
+        auto fast = [](size_t n) { return is_pow2(n) || aeth::fft_ragged_supported(n); };
+        if (fast(a) && fast(b)) { *n1 = a; *n2 = b; return true; }
+        if (!fb1 && (fast(a) || factorize_mixed(a, fac)) && (fast(b) || factorize_mixed(b, fac))) { fb1 = a; fb2 = b; }
+    }
+    if (fb1) { *n1 = fb1; *n2 = fb2; return true; }
+    return false;
+}
+
 int make_twiddles(aeth_ctx *ctx, size_t n, float2 **out_dev)
 {
     std::vector<float2> h(n ? n : 1);
@@ -621,6 +642,7 @@ int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sig
     case FFT_ALGO_MIXED: return launch_mixed(plan, in, out, batch, sign, scale);
     case FFT_ALGO_RAGGED: return fft_run_ragged(plan, in, out, batch, sign, scale);
     case FFT_ALGO_FOURSTEP: return fft_run_fourstep(plan, in, out, batch, sign, scale);
+    case FFT_ALGO_FOURSTEP_MIXED: return fft_run_fourstep_mixed(plan, in, out, batch, sign, scale);
     case FFT_ALGO_BLUESTEIN: return fft_run_bluestein(plan, in, out, batch, sign, scale);
     default: return set_error(AETH_E_UNSUPPORTED, "no kernel path for length %zu", plan->len);
     }
@@ -660,6 +682,10 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
         p->algo = aeth::FFT_ALGO_FOURSTEP;
         p->algo_name = "fourstep_pow2";
         rc = aeth::fft_plan_fourstep(p);
+    } else if (!aeth::tuning_int("AETH_FFT_NO4SMIXED", 0) && split_fourstep_mixed(len, &p->n1, &p->n2)) {
+        p->algo = aeth::FFT_ALGO_FOURSTEP_MIXED;
+        p->algo_name = "fourstep_mixed";
+        rc = aeth::fft_plan_fourstep_mixed(p);
     } else {
         p->algo = aeth::FFT_ALGO_BLUESTEIN;
         p->algo_name = "bluestein";

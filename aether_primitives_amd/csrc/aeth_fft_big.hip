@@ -227,6 +227,57 @@ inline int grid_for(const aeth_ctx *ctx, size_t items)
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// ---- fourstep_mixed: batched transposes around the batched transforms of the two factors ----
+// out[c][r] = in[r][c] (* W_len^(r c) when S != 0) for `batch` frames of R x C; 64 x 64 tiles through LDS, both
+// sides in 512-byte rows.  twN = exp(-2 pi i k / len); r*c < len.
+template <int S, bool NT>
+__global__ __launch_bounds__(256) void transpose_kernel(const cf *in, cf *out, int R, int C, int tr, int tc,
+                                                         const cf *__restrict__ twN)
+{
+    __shared__ cf tile[64][65];
+    const size_t t = blockIdx.x;
+    const int tcx = (int)(t % tc);
+    const size_t t2 = t / tc;
+    const int trx = (int)(t2 % tr);
+    const size_t f = t2 / tr;
+    const int r0 = trx * 64, c0 = tcx * 64;
+    const cf *src = in + f * (size_t)R * C;
+    cf *dst = out + f * (size_t)R * C;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    cf v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int r = r0 + ty + 4 * k, c = c0 + tx;
+        v[k] = (r < R && c < C) ? aeth::nt_load<NT>(src + (size_t)r * C + c) : mk(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) tile[ty + 4 * k][tx] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < R && c < C) {
+            cf w = tile[tx][ty + 4 * k];
+            if constexpr (S != 0) w = ctw<S>(w, twN[(size_t)r * c]);
+            aeth::nt_store<NT>(dst + (size_t)c * R + r, w);
+        }
+    }
+}
+
+template <int S>
+int launch_transpose(const aeth_fft *plan, const float2 *in, float2 *out, size_t R, size_t C, size_t batch)
+{
+    const aeth_ctx *ctx = plan->ctx;
+    const int tr = (int)((R + 63) / 64), tc = (int)((C + 63) / 64);
+    const size_t tiles = batch * (size_t)tr * tc;
+    if (tiles > 0x7fffffffull) return aeth::set_error(AETH_E_UNSUPPORTED, "fourstep_mixed: %zu tiles in one launch", tiles);
+    const bool nt = aeth::streams_past_cache(2 * batch * R * C * sizeof(float2));
+    if (nt) hipLaunchKernelGGL((transpose_kernel<S, true>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const cf *)in, (cf *)out, (int)R, (int)C, tr, tc, (const cf *)plan->tw_dev);
+    else    hipLaunchKernelGGL((transpose_kernel<S, false>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const cf *)in, (cf *)out, (int)R, (int)C, tr, tc, (const cf *)plan->tw_dev);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
 }  // namespace
 
 namespace aeth {
@@ -261,6 +312,36 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
     rc = cols();
     if (rc) return rc;
     return rows();
+}
+
+// ------------------------------- four-step, any two factors ----------------------------
+// len = n1 * n2 with both factors served by a single-workgroup kernel (n1, n2 <= 8192).  Five launches:
+//   x as n1 x n2 -> transpose -> n2 rows of n1: transform each -> times W_len^(n2 k1), transpose -> n1 rows of n2:
+//   transform each (scale fused) -> transpose: X[k1 + n1 k2].
+// 80 B/sample of traffic against Bluestein's two power-of-two four-step transforms of 2-4x the length.
+int fft_plan_fourstep_mixed(aeth_fft *plan)
+{
+    int rc = aeth_fft_create(plan->ctx, plan->n1, 1, &plan->sub1);
+    if (rc) return rc;
+    return aeth_fft_create(plan->ctx, plan->n2, 1, &plan->sub2);
+}
+
+int fft_run_fourstep_mixed(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+{
+    const size_t n1 = plan->n1, n2 = plan->n2, total = plan->len * batch;
+    int rc = ensure_work(plan, 2 * total);
+    if (rc) return rc;
+    float2 *a = plan->work_dev, *b = plan->work_dev + total;
+    rc = launch_transpose<0>(plan, in, a, n1, n2, batch);                       // a[n2][n1]
+    if (rc) return rc;
+    rc = fft_run(plan->sub1, a, a, batch * n2, sign, 1.0f);                      // a[n2][k1]
+    if (rc) return rc;
+    rc = sign > 0 ? launch_transpose<+1>(plan, a, b, n2, n1, batch)             // b[k1][n2] = a[n2][k1] W^(n2 k1)
+                  : launch_transpose<-1>(plan, a, b, n2, n1, batch);
+    if (rc) return rc;
+    rc = fft_run(plan->sub2, b, b, batch * n1, sign, scale);                    // b[k1][k2]
+    if (rc) return rc;
+    return launch_transpose<0>(plan, b, out, n1, n2, batch);                    // out[k2][k1]
 }
 
 // ------------------------------- bluestein --------------------------------------------

@@ -32,13 +32,15 @@ struct aeth_fft {
 
 namespace aeth {
 
-enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_RAGGED = 5 };
+enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_RAGGED = 5, FFT_ALGO_FOURSTEP_MIXED = 6 };
 
 int fft_run(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 int fft_ensure_tmp(aeth_fft *plan, size_t elems);
 
 int fft_plan_fourstep(aeth_fft *plan);
 int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+int fft_plan_fourstep_mixed(aeth_fft *plan);     // n1, n2 set by the caller
+int fft_run_fourstep_mixed(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 int fft_plan_bluestein(aeth_fft *plan);
 int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 void fft_plan_release_children(aeth_fft *plan);

@@ -26,6 +26,8 @@ SMOOTH = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(9) f
 MIXED = [1, 7, 14, 49, 61, 126, 210, 1155, 2401, 4095, 7680, 7776]           # LDS ping-pong kernel
 BIG = [8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
+# above 8192 with two factors of at most 8192: transposes around the batched transforms of the factors
+TWO_FACTOR = [8232, 9600, 10000, 12000, 15360, 20000, 30720, 100000, 196608, 1000000, 2048 * 2025]
 
 
 def _truth(oracle, x, n, sign):
@@ -91,9 +93,11 @@ def test_fft_vs_truth_small(ctx, oracle, n):
             assert bits_equal(d.to_host(), out.to_host())
 
 
-@pytest.mark.parametrize("n", BIG + ODD)
+@pytest.mark.parametrize("n", BIG + ODD + TWO_FACTOR)
 def test_fft_vs_truth_big(ctx, oracle, n):
     f = HipFft(ctx, n)
+    if n in TWO_FACTOR:
+        assert f.algorithm == "fourstep_mixed"
     for sign, batch in ((+1, 1), (-1, 3)):
         x = rand_c64(n + batch, n * batch)
         out = ctx.empty(n * batch)
@@ -127,6 +131,8 @@ def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 126).algorithm == "stockham_mixed"
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
+    assert HipFft(ctx, 10000).algorithm == "fourstep_mixed"
+    assert HipFft(ctx, 2 * 10007).algorithm == "bluestein"
 
 
 @pytest.mark.parametrize("n", [8, 100, 2048, 65536, 97])
