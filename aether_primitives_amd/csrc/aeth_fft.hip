@@ -6,7 +6,8 @@
 //                   frame per T = N/P lanes, data exchanged through LDS between
 //                   passes, twiddles held in registers across a persistent loop over
 //                   frames.  16 B/sample of HBM traffic (8 R + 8 W), scale fused.
-//   stockham_mixed_ragged  every other N = 2^a 3^b 5^c up to 7500: the same idea with
+//   stockham_mixed_ragged  every other N = 2^a 3^b 5^c up to 20480 (one workgroup, up to
+//                   160 KiB of LDS per frame) and 16384: the same idea with
 //                   passes that do not share a lane shape (aeth_fft_ragged.h/.hip),
 //                   one measured decomposition per length.
 //   stockham_mixed  other N <= 8192 with prime factors <= 61: one workgroup per frame,
@@ -14,6 +15,8 @@
 //                   sum/difference form so that constant inputs give exactly-zero
 //                   bins, as the reference's own FFT tests expect: fft.rs:93-104,
 //                   vecops.rs:443-463 at N=100), generic O(r^2) for other primes.
+//   fourstep_mixed  N > 8192 = n1 * n2 with both factors <= 8192: three transposes around
+//                   the batched transforms of the factors (aeth_fft_big.hip).
 //   fourstep_pow2   N = 2^13..2^24: N1 x N2 decomposition, two launches through the
 //                   plan's scratch (BASELINE config 5, N = 65536 = 256 x 256).
 //   bluestein       everything else: chirp-z through a power-of-two convolution.

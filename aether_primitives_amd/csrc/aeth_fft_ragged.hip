@@ -1,5 +1,5 @@
 // aeth_fft_ragged.hip -- the "stockham_mixed_ragged" path of trait Fft (reference src/fft.rs:48-77): every length
-// 2^a 3^b 5^c from 3 to 7500 that is no power of two, one measured decomposition each (aeth_fft_ragged.h has the
+// 2^a 3^b 5^c from 3 to 20480 that is no power of two (and 16384), one measured decomposition each (aeth_fft_ragged.h has the
 // kernel, aeth_fft_ragged_table.inc the table).  The table is compiled in AETH_RAGGED_PARTS slices -- this file
 // once per slice with -DAETH_RAGGED_PART=k -- so that the build spreads over the cores.
 #include "aeth_fft_ragged.h"

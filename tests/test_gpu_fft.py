@@ -20,14 +20,14 @@ KAT = load_kat()
 TOL_DB = -120.0
 
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
-# every length 2^a 3^b 5^c below 7500 that is no power of two: the ragged register-resident table
-SMOOTH = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(9) for c in range(6)
-                 if 3 <= 2 ** a * 3 ** b * 5 ** c <= 7500} - {2 ** k for k in range(14)})
-MIXED = [1, 7, 14, 49, 61, 126, 210, 1155, 2401, 4095, 7680, 7776]           # LDS ping-pong kernel
-BIG = [8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
+# every length 2^a 3^b 5^c up to 20480 that is no power of two, and 16384: the ragged register-resident table
+SMOOTH = sorted(({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10) for c in range(7)
+                  if 3 <= 2 ** a * 3 ** b * 5 ** c <= 20480} - {2 ** k for k in range(15)}) | {16384})
+MIXED = [1, 7, 14, 49, 61, 126, 210, 1155, 2401, 4095, 7203, 8190]           # LDS ping-pong kernel
+BIG = [8192, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
 # above 8192 with two factors of at most 8192: transposes around the batched transforms of the factors
-TWO_FACTOR = [8232, 9600, 10000, 12000, 15360, 20000, 30720, 100000, 196608, 1000000, 2048 * 2025]
+TWO_FACTOR = [8232, 9604, 21000, 23040, 24000, 30720, 100000, 196608, 1000000, 2048 * 2025]
 
 
 def _truth(oracle, x, n, sign):
@@ -83,7 +83,7 @@ def test_fft_vs_truth_small(ctx, oracle, n):
     assert f.len() == n
     if n in SMOOTH:
         assert f.algorithm == "stockham_mixed_ragged"
-    for sign, batch in ((+1, 1), (-1, 1), (+1, 7), (-1, 130)):
+    for sign, batch in ((+1, 1), (-1, 1), (+1, 7), (-1, 130 if n <= 8192 else 9)):
         x = rand_c64(1000 * n + batch + sign, n * batch)
         out = ctx.empty(n * batch)
         f.exec(ctx.vec(x), out, sign)
@@ -107,7 +107,7 @@ def test_fft_vs_truth_big(ctx, oracle, n):
         assert bits_equal(d.to_host(), out.to_host())
 
 
-@pytest.mark.parametrize("n", [3, 12, 25, 100, 120, 480, 1000, 3125, 3600, 6000, 7500])
+@pytest.mark.parametrize("n", [3, 12, 25, 100, 120, 480, 1000, 3125, 3600, 6000, 7500, 10000, 16384, 20480])
 def test_ragged_streaming_batch_matches_small_batches(ctx, n):
     """Batches beyond the cache take the non-temporal instantiation and the persistent grid wraps several times;
     the bits must be those of the same frames transformed a handful at a time."""
@@ -131,7 +131,9 @@ def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 126).algorithm == "stockham_mixed"
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
-    assert HipFft(ctx, 10000).algorithm == "fourstep_mixed"
+    assert HipFft(ctx, 10000).algorithm == "stockham_mixed_ragged"
+    assert HipFft(ctx, 16384).algorithm == "stockham_mixed_ragged"
+    assert HipFft(ctx, 30000).algorithm == "fourstep_mixed"
     assert HipFft(ctx, 2 * 10007).algorithm == "bluestein"
 
 

@@ -13,10 +13,10 @@ from helpers import rand_c64, bits_equal
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = ap.Context(0)
-smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(9) for c in range(6)
-                 if 3 <= 2 ** a * 3 ** b * 5 ** c <= 7500} - {2 ** k for k in range(14)})      # the ragged table
+smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10) for c in range(7)
+                 if 3 <= 2 ** a * 3 ** b * 5 ** c <= 20480} - {2 ** k for k in range(14)})     # the ragged table
 lengths = [2 ** k for k in range(1, 17)] + smooth + [7, 14, 17, 49, 67, 126, 127, 134, 257, 509, 1009, 2039, 2401, 4099,
-                                                     7680, 7776, 8000]
+                                                     7203, 8190, 9604, 23040, 30720, 100000]
 plans, firs = {}, {}
 t0 = last = time.time(); it = 0; worst = -400.0
 while time.time() - t0 < secs:
