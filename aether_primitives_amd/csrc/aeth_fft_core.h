@@ -327,6 +327,30 @@ template <int S> struct Bfly<5, S> {
     }
 };
 
+template <int S> struct Bfly<7, S> {
+    static __device__ __forceinline__ void run(cf (&u)[7])
+    {
+        constexpr float c1 = (float)c_cos(2 * kPiD / 7), c2 = (float)c_cos(4 * kPiD / 7), c3 = (float)c_cos(6 * kPiD / 7);
+        constexpr float s1 = (float)c_sin(2 * kPiD / 7), s2 = (float)c_sin(4 * kPiD / 7), s3 = (float)c_sin(6 * kPiD / 7);
+        const cf t1 = cadd(u[1], u[6]), t2 = cadd(u[2], u[5]), t3 = cadd(u[3], u[4]);
+        const cf d1 = csub(u[1], u[6]), d2 = csub(u[2], u[5]), d3 = csub(u[3], u[4]);
+        const cf y0 = cadd(cadd(u[0], t1), cadd(t2, t3));
+        const cf a1 = u[0] + t1 * c1 + t2 * c2 + t3 * c3;
+        const cf a2 = u[0] + t1 * c2 + t2 * c3 + t3 * c1;
+        const cf a3 = u[0] + t1 * c3 + t2 * c1 + t3 * c2;
+        const cf b1 = d1 * s1 + d2 * s2 + d3 * s3;
+        const cf b2 = d1 * s2 - d2 * s3 - d3 * s1;
+        const cf b3 = d1 * s3 - d2 * s1 + d3 * s2;
+        u[0] = y0;
+        u[1] = cadd_rot<S>(a1, b1);
+        u[6] = csub_rot<S>(a1, b1);
+        u[2] = cadd_rot<S>(a2, b2);
+        u[5] = csub_rot<S>(a2, b2);
+        u[3] = cadd_rot<S>(a3, b3);
+        u[4] = csub_rot<S>(a3, b3);
+    }
+};
+
 // R = R1*R2:  X[k1 + R1*k2] = sum_n2 W_R2^(n2 k2) [ W_R^(n2 k1) sum_n1 x[n1*R2 + n2] W_R1^(n1 k1) ]
 // the inner twiddles W_R^(n2 k1) are compile-time constants held in SGPR pairs
 template <int R1, int R2, int S> struct BflyC {
@@ -373,6 +397,9 @@ template <int S> struct Bfly<18, S> : BflyC<6, 3, S> {};
 template <int S> struct Bfly<27, S> : BflyC<9, 3, S> {};
 template <int S> struct Bfly<30, S> : BflyC<6, 5, S> {};
 template <int S> struct Bfly<32, S> : BflyC<8, 4, S> {};
+template <int S> struct Bfly<14, S> : BflyC<7, 2, S> {};
+template <int S> struct Bfly<21, S> : BflyC<7, 3, S> {};
+template <int S> struct Bfly<28, S> : BflyC<7, 4, S> {};
 
 // ---- compile-time description of one transform size ---------------------------
 // WG_ = 0: the power-of-two rule (T lanes, at least 64).  WG_ > 0: that many lanes; F = WG / T frames, the

@@ -15,7 +15,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = ap.Context(0)
 smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10) for c in range(7)
                  if 3 <= 2 ** a * 3 ** b * 5 ** c <= 20480} - {2 ** k for k in range(14)})     # the ragged table
-lengths = [2 ** k for k in range(1, 17)] + smooth + [7, 14, 17, 49, 67, 126, 127, 134, 257, 509, 1009, 2039, 2401, 4099,
+seven = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(13) for b in range(8) for c in range(6) for d in range(1, 5)
+                if 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096})
+lengths = [2 ** k for k in range(1, 17)] + smooth + seven + [11, 13, 17, 22, 67, 127, 134, 143, 257, 509, 1009, 2039, 4099, 4116,
                                                      7203, 8190, 9604, 23040, 30720, 100000]
 plans, firs = {}, {}
 t0 = last = time.time(); it = 0; worst = -400.0
