@@ -52,10 +52,10 @@ report("vec_mirror_frames(2048) n=2^25", 16 * n, timeit(lambda i: A[i % NB].vec_
 v, a, b = ctx.vec(host[:4096]), ctx.vec(host[4096:8192]), ctx.vec(host[8192:12288])
 report("C1 chain add->mul->conj n=4096 (3 launches)", 64 * 4096, timeit(lambda i: v.vec_add(a).vec_mul(b).vec_conj(), reps=50), 4096)
 
-for N in (512, 1024, 2048, 4096, 100, 1000):
+for N in (512, 1024, 2048, 4096, 12, 100, 126, 143, 960, 1000, 1536, 3600, 6000, 10000, 16384, 20480, 30720):
     f = ap.HipFft(ctx, N)
     m = (n // N) * N
-    report(f"fft ifwd N={N} batch={m // N}", 16 * m, timeit(lambda i: f.ifwd(A[i % NB].slice(0, m), Scale.SN)), m)
+    report(f"fft ifwd N={N} batch={m // N} ({f.algorithm})", 16 * m, timeit(lambda i: f.ifwd(A[i % NB].slice(0, m), Scale.SN)), m)
 f = ap.HipFft(ctx, 2048)
 report("fft fwd (out of place) N=2048", 16 * n, timeit(lambda i: f.fwd(A[i % NB], B[i % NB], Scale.SN)), n)
 c2 = [ctx.vec(host[:1 << 20]) for _ in range(2)]
