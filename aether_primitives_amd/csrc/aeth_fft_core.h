@@ -351,6 +351,51 @@ template <int S> struct Bfly<7, S> {
     }
 };
 
+// odd prime P by the definition, folded over the pairs (k, P-k): (P-1)^2/2 real-by-complex multiply-adds with the
+// cosines and sines from a compile-time table (11 and 13: beyond that the LDS kernel's generic pass)
+template <int P> struct OddPrimeTable {
+    float c[P], s[P];
+    constexpr OddPrimeTable() : c{}, s{}
+    {
+        for (int i = 0; i < P; i++) {
+            c[i] = (float)c_cos(2 * kPiD * (double)i / (double)P);
+            s[i] = (float)c_sin(2 * kPiD * (double)i / (double)P);
+        }
+    }
+};
+
+template <int P, int S> struct BflyOddPrime {
+    static __device__ __forceinline__ void run(cf (&u)[P])
+    {
+        constexpr int H = (P - 1) / 2;
+        constexpr OddPrimeTable<P> tab{};
+        cf t[H], d[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            t[k] = cadd(u[k + 1], u[P - 1 - k]);
+            d[k] = csub(u[k + 1], u[P - 1 - k]);
+        }
+        const cf x0 = u[0];
+        cf y0 = x0;
+#pragma unroll
+        for (int k = 0; k < H; k++) y0 = cadd(y0, t[k]);
+        u[0] = y0;
+#pragma unroll
+        for (int m = 1; m <= H; m++) {
+            cf a = x0, b = mk(0.f, 0.f);
+#pragma unroll
+            for (int k = 1; k <= H; k++) {
+                a = a + t[k - 1] * tab.c[(m * k) % P];
+                b = b + d[k - 1] * tab.s[(m * k) % P];
+            }
+            u[m] = cadd_rot<S>(a, b);
+            u[P - m] = csub_rot<S>(a, b);
+        }
+    }
+};
+template <int S> struct Bfly<11, S> : BflyOddPrime<11, S> {};
+template <int S> struct Bfly<13, S> : BflyOddPrime<13, S> {};
+
 // R = R1*R2:  X[k1 + R1*k2] = sum_n2 W_R2^(n2 k2) [ W_R^(n2 k1) sum_n1 x[n1*R2 + n2] W_R1^(n1 k1) ]
 // the inner twiddles W_R^(n2 k1) are compile-time constants held in SGPR pairs
 template <int R1, int R2, int S> struct BflyC {
@@ -400,6 +445,8 @@ template <int S> struct Bfly<32, S> : BflyC<8, 4, S> {};
 template <int S> struct Bfly<14, S> : BflyC<7, 2, S> {};
 template <int S> struct Bfly<21, S> : BflyC<7, 3, S> {};
 template <int S> struct Bfly<28, S> : BflyC<7, 4, S> {};
+template <int S> struct Bfly<22, S> : BflyC<11, 2, S> {};
+template <int S> struct Bfly<26, S> : BflyC<13, 2, S> {};
 
 // ---- compile-time description of one transform size ---------------------------
 // WG_ = 0: the power-of-two rule (T lanes, at least 64).  WG_ > 0: that many lanes; F = WG / T frames, the

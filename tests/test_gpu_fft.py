@@ -25,8 +25,12 @@ POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 SMOOTH = sorted(({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10) for c in range(7)
                   if 3 <= 2 ** a * 3 ** b * 5 ** c <= 20480} - {2 ** k for k in range(15)}) | {16384}
                 | {2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(13) for b in range(8) for c in range(6) for d in range(1, 5)
-                   if 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096})
-MIXED = [1, 11, 13, 22, 61, 121, 143, 1155, 4095, 4116, 7203, 8190]           # LDS ping-pong kernel
+                   if 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096}
+                # ... and every 13-smooth length up to 2048 with a factor 11 or 13
+                | {2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f for a in range(12) for b in range(7) for c in range(5)
+                   for d in range(4) for e in range(3) for f in range(3)
+                   if e + f >= 1 and 2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f <= 2048})
+MIXED = [1, 17, 19, 34, 61, 289, 323, 2079, 4095, 4116, 7203, 8190]           # LDS ping-pong kernel
 BIG = [8192, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
 # above 8192 with two factors of at most 8192: transposes around the batched transforms of the factors
@@ -110,7 +114,7 @@ def test_fft_vs_truth_big(ctx, oracle, n):
         assert bits_equal(d.to_host(), out.to_host())
 
 
-@pytest.mark.parametrize("n", [3, 7, 12, 25, 100, 120, 196, 480, 1000, 2401, 3125, 3600, 6000, 7500, 10000, 16384, 20480])
+@pytest.mark.parametrize("n", [3, 7, 11, 12, 25, 100, 120, 143, 196, 480, 1000, 2002, 2401, 3125, 3600, 6000, 7500, 10000, 16384, 20480])
 def test_ragged_streaming_batch_matches_small_batches(ctx, n):
     """Batches beyond the cache take the non-temporal instantiation and the persistent grid wraps several times;
     the bits must be those of the same frames transformed a handful at a time."""
@@ -132,7 +136,8 @@ def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 2048).algorithm == "stockham_pow2"
     assert HipFft(ctx, 100).algorithm == "stockham_mixed_ragged"
     assert HipFft(ctx, 126).algorithm == "stockham_mixed_ragged"
-    assert HipFft(ctx, 143).algorithm == "stockham_mixed"
+    assert HipFft(ctx, 143).algorithm == "stockham_mixed_ragged"
+    assert HipFft(ctx, 323).algorithm == "stockham_mixed"
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
     assert HipFft(ctx, 10000).algorithm == "stockham_mixed_ragged"

@@ -17,7 +17,10 @@ smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10) 
                  if 3 <= 2 ** a * 3 ** b * 5 ** c <= 20480} - {2 ** k for k in range(14)})     # the ragged table
 seven = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(13) for b in range(8) for c in range(6) for d in range(1, 5)
                 if 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096})
-lengths = [2 ** k for k in range(1, 17)] + smooth + seven + [11, 13, 17, 22, 67, 127, 134, 143, 257, 509, 1009, 2039, 4099, 4116,
+eleven = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f for a in range(12) for b in range(7) for c in range(5)
+                 for d in range(4) for e in range(3) for f in range(3)
+                 if e + f >= 1 and 2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f <= 2048})
+lengths = [2 ** k for k in range(1, 17)] + smooth + seven + eleven + [17, 19, 34, 67, 127, 134, 323, 257, 509, 1009, 2039, 4099, 4116,
                                                      7203, 8190, 9604, 23040, 30720, 100000]
 plans, firs = {}, {}
 t0 = last = time.time(); it = 0; worst = -400.0
