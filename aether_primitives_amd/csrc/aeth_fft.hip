@@ -7,7 +7,8 @@
 //                   passes, twiddles held in registers across a persistent loop over
 //                   frames.  16 B/sample of HBM traffic (8 R + 8 W), scale fused.
 //   stockham_mixed_ragged  every other N = 2^a 3^b 5^c up to 20480 (one workgroup, up to
-//                   160 KiB of LDS per frame) and 16384: the same idea with
+//                   160 KiB of LDS per frame), 16384, factor 7 up to 4096, factors 11 / 13
+//                   up to 2048: the same idea with
 //                   passes that do not share a lane shape (aeth_fft_ragged.h/.hip),
 //                   one measured decomposition per length.
 //   stockham_mixed  other N <= 8192 with prime factors <= 61: one workgroup per frame,
