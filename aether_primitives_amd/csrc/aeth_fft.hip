@@ -564,6 +564,12 @@ bool factorize_mixed(size_t n, std::vector<int> &fac)
 // LDS mixed-radix kernel can do.
 bool split_fourstep_mixed(size_t len, size_t *n1, size_t *n2)
 {
+    auto fast = [](size_t n) { return (is_pow2(n) && n <= 8192) || aeth::fft_ragged_supported(n); };
+    // a small first factor over one register-resident transform (up to 20480 points): no transposes
+    for (size_t r = 2; r <= 16; r++) {
+        if (!aeth::fourstep_small_factor(r) || len % r) continue;
+        if (fast(len / r)) { *n1 = r; *n2 = len / r; return true; }
+    }
     size_t root = 1;
     while ((root + 1) * (root + 1) <= len) root++;
     size_t fb1 = 0, fb2 = 0;
@@ -572,7 +578,6 @@ bool split_fourstep_mixed(size_t len, size_t *n1, size_t *n2)
         if (len % a) continue;
         const size_t b = len / a;
         if (b > 8192) break;
-        auto fast = [](size_t n) { return is_pow2(n) || aeth::fft_ragged_supported(n); };
         if (fast(a) && fast(b)) { *n1 = a; *n2 = b; return true; }
         if (!fb1 && (fast(a) || factorize_mixed(a, fac)) && (fast(b) || factorize_mixed(b, fac))) { fb1 = a; fb2 = b; }
     }

@@ -278,6 +278,79 @@ int launch_transpose(const aeth_fft *plan, const float2 *in, float2 *out, size_t
     return AETH_OK;
 }
 
+// ---- fourstep_mixed with a small first factor R: no transposes ----
+// step A: the R-point transforms down the columns of the R x M frame, times W_len^(c k1); one lane per column,
+// rows M elements apart, so every access is a coalesced row segment
+template <int R, int S, bool NT>
+__global__ __launch_bounds__(256) void smallcol_kernel(const cf *in, cf *out, size_t M, size_t cols,
+                                                        const cf *__restrict__ twN)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;       // frame * M + column
+    if (g >= cols) return;
+    const size_t f = g / M, c = g - f * M;
+    const cf *src = in + f * R * M + c;
+    cf *dst = out + f * R * M + c;
+    cf u[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) u[r] = aeth::nt_load<NT>(src + r * M);
+    Bfly<R, S>::run(u);
+#pragma unroll
+    for (int k = 1; k < R; k++) u[k] = ctw<S>(u[k], twN[c * k]);
+#pragma unroll
+    for (int k = 0; k < R; k++) aeth::nt_store<NT>(dst + k * M, u[k]);
+}
+
+// step C: X[k1 + R k2] = b[k1][k2].  Frame f, column c sits at g = f M + c and its R outputs at out[g R ...], so a
+// block of 256 columns owns 256 R consecutive outputs: gathered through LDS (one pad slot per 16 elements), stored
+// in whole rows
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void interleave_kernel(const cf *in, cf *out, size_t M, size_t cols)
+{
+    __shared__ cf tile[256 * R + 256 * R / 16 + 1];
+    const size_t g0 = (size_t)blockIdx.x * 256;
+    const size_t g = g0 + threadIdx.x;                              // frame * M + k2
+    const bool live = g < cols;
+    const size_t f = live ? g / M : 0, c = live ? g - f * M : 0;
+    const cf *src = in + f * R * M + c;
+    cf u[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) u[r] = live ? aeth::nt_load<NT>(src + r * M) : mk(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = (int)threadIdx.x * R + r;
+        tile[e + (e >> 4)] = u[r];
+    }
+    __syncthreads();
+    const size_t have = (cols - g0 < 256 ? cols - g0 : 256) * R;   // outputs this block owns
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int e = j * 256 + (int)threadIdx.x;
+        if ((size_t)e < have) aeth::nt_store<NT>(out + g0 * R + e, tile[e + (e >> 4)]);
+    }
+}
+
+template <int R>
+int run_small_first_factor(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+{
+    const aeth_ctx *ctx = plan->ctx;
+    const size_t M = plan->n2, cols = batch * M;
+    const unsigned blocks = (unsigned)((cols + 255) / 256);
+    if ((cols + 255) / 256 > 0x7fffffffull) return aeth::set_error(AETH_E_UNSUPPORTED, "fourstep_mixed: batch too large");
+    const bool nt = aeth::streams_past_cache(2 * batch * plan->len * sizeof(float2));
+    float2 *a = plan->work_dev;
+#define AETH_SC(SS, NN) hipLaunchKernelGGL((smallcol_kernel<R, SS, NN>), dim3(blocks), dim3(256), 0, ctx->stream, (const cf *)in, (cf *)a, M, cols, (const cf *)plan->tw_dev)
+    if (sign > 0) { if (nt) AETH_SC(+1, true); else AETH_SC(+1, false); }
+    else          { if (nt) AETH_SC(-1, true); else AETH_SC(-1, false); }
+#undef AETH_SC
+    AETH_HIP(hipGetLastError());
+    int rc = aeth::fft_run(plan->sub2, a, a, batch * R, sign, scale);
+    if (rc) return rc;
+    if (nt) hipLaunchKernelGGL((interleave_kernel<R, true>), dim3(blocks), dim3(256), 0, ctx->stream, (const cf *)a, (cf *)out, M, cols);
+    else    hipLaunchKernelGGL((interleave_kernel<R, false>), dim3(blocks), dim3(256), 0, ctx->stream, (const cf *)a, (cf *)out, M, cols);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
 }  // namespace
 
 namespace aeth {
@@ -319,16 +392,42 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
 //   x as n1 x n2 -> transpose -> n2 rows of n1: transform each -> times W_len^(n2 k1), transpose -> n1 rows of n2:
 //   transform each (scale fused) -> transpose: X[k1 + n1 k2].
 // 80 B/sample of traffic against Bluestein's two power-of-two four-step transforms of 2-4x the length.
+bool fourstep_small_factor(size_t r)
+{
+    switch (r) { case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 12: case 15: case 16: return true; default: return false; }
+}
+
 int fft_plan_fourstep_mixed(aeth_fft *plan)
 {
-    int rc = aeth_fft_create(plan->ctx, plan->n1, 1, &plan->sub1);
-    if (rc) return rc;
+    if (!fourstep_small_factor(plan->n1)) {
+        int rc = aeth_fft_create(plan->ctx, plan->n1, 1, &plan->sub1);
+        if (rc) return rc;
+    }
     return aeth_fft_create(plan->ctx, plan->n2, 1, &plan->sub2);
 }
 
 int fft_run_fourstep_mixed(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
     const size_t n1 = plan->n1, n2 = plan->n2, total = plan->len * batch;
+    if (fourstep_small_factor(n1)) {
+        // small first factor: columns in registers, no transposes -- three launches, 48 B/sample
+        int rc = ensure_work(plan, total);
+        if (rc) return rc;
+        switch (n1) {
+        case 2: return run_small_first_factor<2>(plan, in, out, batch, sign, scale);
+        case 3: return run_small_first_factor<3>(plan, in, out, batch, sign, scale);
+        case 4: return run_small_first_factor<4>(plan, in, out, batch, sign, scale);
+        case 5: return run_small_first_factor<5>(plan, in, out, batch, sign, scale);
+        case 6: return run_small_first_factor<6>(plan, in, out, batch, sign, scale);
+        case 7: return run_small_first_factor<7>(plan, in, out, batch, sign, scale);
+        case 8: return run_small_first_factor<8>(plan, in, out, batch, sign, scale);
+        case 9: return run_small_first_factor<9>(plan, in, out, batch, sign, scale);
+        case 10: return run_small_first_factor<10>(plan, in, out, batch, sign, scale);
+        case 12: return run_small_first_factor<12>(plan, in, out, batch, sign, scale);
+        case 15: return run_small_first_factor<15>(plan, in, out, batch, sign, scale);
+        default: return run_small_first_factor<16>(plan, in, out, batch, sign, scale);
+        }
+    }
     int rc = ensure_work(plan, 2 * total);
     if (rc) return rc;
     float2 *a = plan->work_dev, *b = plan->work_dev + total;

@@ -39,6 +39,7 @@ int fft_ensure_tmp(aeth_fft *plan, size_t elems);
 
 int fft_plan_fourstep(aeth_fft *plan);
 int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
+bool fourstep_small_factor(size_t r);             // first factors the transpose-free path handles in registers
 int fft_plan_fourstep_mixed(aeth_fft *plan);     // n1, n2 set by the caller
 int fft_run_fourstep_mixed(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale);
 int fft_plan_bluestein(aeth_fft *plan);
