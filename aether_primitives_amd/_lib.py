@@ -27,6 +27,8 @@ PROTOTYPES = {
     "aeth_ctx_create_on_stream": (i32, [i32, vp, pvp]),
     "aeth_ctx_destroy": (i32, [vp]),
     "aeth_ctx_sync": (i32, [vp]),
+    "aeth_ctx_set_overlap": (i32, [vp, i32]),
+    "aeth_ctx_overlap": (i32, [vp]),
     "aeth_ctx_stream": (vp, [vp]),
     "aeth_ctx_device": (i32, [vp]),
     "aeth_dev_alloc": (i32, [vp, sz, pvp]),

@@ -46,6 +46,15 @@ class Context:
     def sync(self):
         check(self._lib.aeth_ctx_sync(self.h))
 
+    def set_overlap(self, enable=True):
+        """Let consecutive independent `Fir.filter` launches alternate between two HIP queues (the end of one
+        launch then runs beside the start of the next); everything else stays ordered as on one stream."""
+        check(self._lib.aeth_ctx_set_overlap(self.h, 1 if enable else 0))
+
+    @property
+    def overlap(self):
+        return bool(self._lib.aeth_ctx_overlap(self.h))
+
     @property
     def stream(self):
         return self._lib.aeth_ctx_stream(self.h)

@@ -188,7 +188,7 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
         int grid2 = (int)(batch < cap2 ? batch : cap2);
         if (grid2 < 1) grid2 = 1;
         if (!aeth::tuning_int("AETH_FFT_NOSTREAM", 0)) {
-#define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+#define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
             if (sign > 0) { if (nt) AETH_FFT_STREAM(+1, true); else AETH_FFT_STREAM(+1, false); }
             else          { if (nt) AETH_FFT_STREAM(-1, true); else AETH_FFT_STREAM(-1, false); }
 #undef AETH_FFT_STREAM
@@ -196,7 +196,7 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
             return AETH_OK;
         }
     }
-#define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+#define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
     if (sign > 0) { if (nt) AETH_FFT_PLAIN(+1, true); else AETH_FFT_PLAIN(+1, false); }
     else          { if (nt) AETH_FFT_PLAIN(-1, true); else AETH_FFT_PLAIN(-1, false); }
 #undef AETH_FFT_PLAIN
@@ -216,10 +216,10 @@ int build_lane_table(aeth_fft *plan)
 {
     const size_t elems = (size_t)LaneTable<C>::ELEMS;
     AETH_HIP(hipMalloc((void **)&plan->tw_lane_dev, elems * sizeof(float2)));
-    hipLaunchKernelGGL((build_lane_twiddles<C>), dim3(1), dim3(C::T < 64 ? 64 : C::T), 0, plan->ctx->stream,
+    hipLaunchKernelGGL((build_lane_twiddles<C>), dim3(1), dim3(C::T < 64 ? 64 : C::T), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)plan->tw_dev, (cf *)plan->tw_lane_dev);
     AETH_HIP(hipGetLastError());
-    AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(plan->ctx)));
     return AETH_OK;
 }
 
@@ -531,7 +531,7 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
         shmem += (size_t)off * sizeof(cf);
     }
 #define AETH_MIXED_LAUNCH(SW, IP)                                                                                        \
-    hipLaunchKernelGGL((fft_mixed_kernel<SW, IP>), dim3(grid), dim3(kMixedWG), shmem, ctx->stream, (const cf *)in,       \
+    hipLaunchKernelGGL((fft_mixed_kernel<SW, IP>), dim3(grid), dim3(kMixedWG), shmem, aeth::ctx_stream(ctx), (const cf *)in,       \
                        (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds)
 #define AETH_MIXED_SIGN(IP) do { if (sign > 0) AETH_MIXED_LAUNCH(true, IP); else AETH_MIXED_LAUNCH(false, IP); } while (0)
     switch (pts) {
@@ -593,8 +593,8 @@ int make_twiddles(aeth_ctx *ctx, size_t n, float2 **out_dev)
         h[k] = make_float2((float)cos(a), (float)sin(a));
     }
     AETH_HIP(hipMalloc((void **)out_dev, h.size() * sizeof(float2)));
-    AETH_HIP(hipMemcpyAsync(*out_dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipMemcpyAsync(*out_dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 
@@ -618,8 +618,8 @@ int plan_mixed(aeth_fft *plan)
     }
     if (h.empty()) h.push_back(make_float2(1.f, 0.f));
     AETH_HIP(hipMalloc((void **)&plan->tw_pass_dev, h.size() * sizeof(float2)));
-    AETH_HIP(hipMemcpyAsync(plan->tw_pass_dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, plan->ctx->stream));
-    AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+    AETH_HIP(hipMemcpyAsync(plan->tw_pass_dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, aeth::ctx_stream(plan->ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(plan->ctx)));
     return AETH_OK;
 }
 
@@ -631,7 +631,7 @@ int fft_ensure_tmp(aeth_fft *plan, size_t elems)
 {
     if (plan->tmp_elems >= elems) return AETH_OK;
     if (plan->tmp_dev) {
-        AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+        AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(plan->ctx)));
         AETH_HIP(hipFree(plan->tmp_dev));
         plan->tmp_dev = nullptr;
         plan->tmp_elems = 0;
@@ -718,7 +718,7 @@ int aeth_fft_destroy(aeth_fft *p)
 {
     if (!p) return AETH_OK;
     aeth::DeviceGuard g(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);
+    (void)hipStreamSynchronize(aeth::ctx_stream(p->ctx));
     aeth::fft_plan_release_children(p);
     if (p->tw_dev) (void)hipFree(p->tw_dev);
     if (p->tw_lane_dev) (void)hipFree(p->tw_lane_dev);
@@ -776,7 +776,7 @@ int aeth_fft_exec_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 
     AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
     AETH_REQUIRE(n_out == p->len, AETH_E_LEN, "Output and FFT must be the same length");
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
-    hipStream_t st = p->ctx->stream;
+    hipStream_t st = aeth::ctx_stream(p->ctx);
     const size_t bytes = p->len * sizeof(float2);
     AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));   /* tmp[..len] <- input, fft.rs:168 */
     const float s = aeth_scale_factor(kind, p->len, x);
@@ -794,7 +794,7 @@ int aeth_fft_exec_tmp_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, int si
     *view = nullptr;
     AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
     AETH_REQUIRE(in, AETH_E_ARG, "null pointer");
-    hipStream_t st = p->ctx->stream;
+    hipStream_t st = aeth::ctx_stream(p->ctx);
     const size_t bytes = p->len * sizeof(float2);
     AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));
     const float s = aeth_scale_factor(kind, p->len, x);

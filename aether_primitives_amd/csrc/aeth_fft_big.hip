@@ -143,7 +143,7 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch)
     const size_t grid = batch * (plan->n2 / G);
     const bool nt = aeth::streams_past_cache(plan->len * batch * sizeof(float2) * 4 / 3);   // from 96 MiB: x, a and X together pass the cache
     auto kern = nt ? fourstep_cols<C, S, true> : fourstep_cols<C, S, false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
                        aeth::tuning_int("AETH_4S_NOTW", 0) ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
     AETH_HIP(hipGetLastError());
@@ -157,7 +157,7 @@ int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale)
     const size_t grid = batch * (plan->n1 / G);
     const bool nt = aeth::streams_past_cache(plan->len * batch * sizeof(float2) * 4 / 3);
     auto kern = nt ? fourstep_rows<C, S, true> : fourstep_rows<C, S, false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, plan->ctx->stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)plan->work_dev, (cf *)out, (const cf *)plan->sub2->tw_lane_dev, (int)plan->n1,
                        plan->len, scale);
     AETH_HIP(hipGetLastError());
@@ -168,7 +168,7 @@ int ensure_work(aeth_fft *plan, size_t elems)
 {
     if (plan->work_elems >= elems) return AETH_OK;
     if (plan->work_dev) {
-        AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+        AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(plan->ctx)));
         AETH_HIP(hipFree(plan->work_dev));
         plan->work_dev = nullptr;
         plan->work_elems = 0;
@@ -272,8 +272,8 @@ int launch_transpose(const aeth_fft *plan, const float2 *in, float2 *out, size_t
     const size_t tiles = batch * (size_t)tr * tc;
     if (tiles > 0x7fffffffull) return aeth::set_error(AETH_E_UNSUPPORTED, "fourstep_mixed: %zu tiles in one launch", tiles);
     const bool nt = aeth::streams_past_cache(2 * batch * R * C * sizeof(float2));
-    if (nt) hipLaunchKernelGGL((transpose_kernel<S, true>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const cf *)in, (cf *)out, (int)R, (int)C, tr, tc, (const cf *)plan->tw_dev);
-    else    hipLaunchKernelGGL((transpose_kernel<S, false>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const cf *)in, (cf *)out, (int)R, (int)C, tr, tc, (const cf *)plan->tw_dev);
+    if (nt) hipLaunchKernelGGL((transpose_kernel<S, true>), dim3((unsigned)tiles), dim3(256), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (int)R, (int)C, tr, tc, (const cf *)plan->tw_dev);
+    else    hipLaunchKernelGGL((transpose_kernel<S, false>), dim3((unsigned)tiles), dim3(256), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (int)R, (int)C, tr, tc, (const cf *)plan->tw_dev);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -338,15 +338,15 @@ int run_small_first_factor(aeth_fft *plan, const float2 *in, float2 *out, size_t
     if ((cols + 255) / 256 > 0x7fffffffull) return aeth::set_error(AETH_E_UNSUPPORTED, "fourstep_mixed: batch too large");
     const bool nt = aeth::streams_past_cache(2 * batch * plan->len * sizeof(float2));
     float2 *a = plan->work_dev;
-#define AETH_SC(SS, NN) hipLaunchKernelGGL((smallcol_kernel<R, SS, NN>), dim3(blocks), dim3(256), 0, ctx->stream, (const cf *)in, (cf *)a, M, cols, (const cf *)plan->tw_dev)
+#define AETH_SC(SS, NN) hipLaunchKernelGGL((smallcol_kernel<R, SS, NN>), dim3(blocks), dim3(256), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)a, M, cols, (const cf *)plan->tw_dev)
     if (sign > 0) { if (nt) AETH_SC(+1, true); else AETH_SC(+1, false); }
     else          { if (nt) AETH_SC(-1, true); else AETH_SC(-1, false); }
 #undef AETH_SC
     AETH_HIP(hipGetLastError());
     int rc = aeth::fft_run(plan->sub2, a, a, batch * R, sign, scale);
     if (rc) return rc;
-    if (nt) hipLaunchKernelGGL((interleave_kernel<R, true>), dim3(blocks), dim3(256), 0, ctx->stream, (const cf *)a, (cf *)out, M, cols);
-    else    hipLaunchKernelGGL((interleave_kernel<R, false>), dim3(blocks), dim3(256), 0, ctx->stream, (const cf *)a, (cf *)out, M, cols);
+    if (nt) hipLaunchKernelGGL((interleave_kernel<R, true>), dim3(blocks), dim3(256), 0, aeth::ctx_stream(ctx), (const cf *)a, (cf *)out, M, cols);
+    else    hipLaunchKernelGGL((interleave_kernel<R, false>), dim3(blocks), dim3(256), 0, aeth::ctx_stream(ctx), (const cf *)a, (cf *)out, M, cols);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -489,8 +489,8 @@ int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batc
     cf *a = (cf *)plan->work_dev;
     const dim3 b(kBlock);
     // DFT+(x) = conj(DFT-(conj x))
-    if (sign > 0) hipLaunchKernelGGL((blu_pre<true>), dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
-    else          hipLaunchKernelGGL((blu_pre<false>), dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
+    if (sign > 0) hipLaunchKernelGGL((blu_pre<true>), dim3(grid_for(ctx, M * batch)), b, 0, aeth::ctx_stream(ctx), (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
+    else          hipLaunchKernelGGL((blu_pre<false>), dim3(grid_for(ctx, M * batch)), b, 0, aeth::ctx_stream(ctx), (const cf *)in, (const cf *)plan->blu_chirp, a, N, M, batch);
     AETH_HIP(hipGetLastError());
     if (plan->blu_sub->algo == FFT_ALGO_POW2 && M <= 4096) {
         // circular convolution in ONE launch of the fused transform * filter * inverse kernel.  It runs +j then
@@ -502,13 +502,13 @@ int fft_run_bluestein(aeth_fft *plan, const float2 *in, float2 *out, size_t batc
     } else {
         rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, -1, 1.0f);
         if (rc) return rc;
-        hipLaunchKernelGGL(blu_mul, dim3(grid_for(ctx, M * batch)), b, 0, ctx->stream, a, (const cf *)plan->blu_filt, M, batch);
+        hipLaunchKernelGGL(blu_mul, dim3(grid_for(ctx, M * batch)), b, 0, aeth::ctx_stream(ctx), a, (const cf *)plan->blu_filt, M, batch);
         AETH_HIP(hipGetLastError());
         rc = fft_run(plan->blu_sub, plan->work_dev, plan->work_dev, batch, +1, 1.0f);
         if (rc) return rc;
     }
-    if (sign > 0) hipLaunchKernelGGL((blu_post<true>), dim3(grid_for(ctx, N * batch)), b, 0, ctx->stream, (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
-    else          hipLaunchKernelGGL((blu_post<false>), dim3(grid_for(ctx, N * batch)), b, 0, ctx->stream, (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
+    if (sign > 0) hipLaunchKernelGGL((blu_post<true>), dim3(grid_for(ctx, N * batch)), b, 0, aeth::ctx_stream(ctx), (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
+    else          hipLaunchKernelGGL((blu_post<false>), dim3(grid_for(ctx, N * batch)), b, 0, aeth::ctx_stream(ctx), (const cf *)a, (const cf *)plan->blu_chirp, (cf *)out, N, M, batch, scale);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

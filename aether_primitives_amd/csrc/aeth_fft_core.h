@@ -576,14 +576,18 @@ __global__ void build_lane_twiddles(const cf *__restrict__ twN, cf *__restrict__
 // read k; image k is next written only after the barrier of exchange k+1, which every
 // lane passes after it has finished reading image k).  With a single image a second
 // barrier in front of the writes keeps late readers safe.
-template <class C, int PASS, int S, int PAR>
+// XP (tuning): bit 0: the exchange runs at s_setprio 1, the butterflies at 0; bit 1: no barriers, bit 2: no LDS
+// traffic at all (both diagnosis only, wrong results)
+template <class C, int PASS, int S, int PAR, int XP = 0>
 __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], cf *__restrict__ lds, int tid)
 {
     constexpr int R = C::radix(PASS), B = C::P / R, p = C::pbefore(PASS);
     constexpr bool last = (PASS == C::NPASS - 1);
+    constexpr bool NOLDS = (XP & 4) != 0;
     cf *img = lds;
-    if constexpr (!last) {
+    if constexpr (!last && !NOLDS) {
         if constexpr (C::DB) img = lds + (((PAR + PASS) & 1) ? C::LDS_ELEMS : 0);
+        else if constexpr (XP & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         else __syncthreads();               // earlier readers of the single image are done
     }
 #pragma unroll
@@ -596,7 +600,7 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
             for (int r = 1; r < R; r++) u[r] = ctw<S>(u[r], tw[C::twoff(PASS) + b * (R - 1) + (r - 1)]);
         }
         Bfly<R, S>::run(u);
-        if constexpr (last) {
+        if constexpr (last || NOLDS) {
 #pragma unroll
             for (int r = 0; r < R; r++) w[b + r * B] = u[r];
         } else {
@@ -607,23 +611,26 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
             for (int r = 0; r < R; r++) img[lidx(j + r * p)] = u[r];
         }
     }
-    if constexpr (!last) {
-        __syncthreads();
+    if constexpr (!last && !NOLDS) {
+        if constexpr (XP & 1) __builtin_amdgcn_s_setprio(1);
+        if constexpr (XP & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        else __syncthreads();
 #pragma unroll
         for (int m = 0; m < C::P; m++) w[m] = img[lidx(tid + m * C::T)];
+        if constexpr (XP & 1) __builtin_amdgcn_s_setprio(0);
     }
 }
 
 // full transform of the frame held in w[] (slot m = element tid + m*T), exponent sign S.
 // PAR = parity of the number of exchanges done so far on this LDS allocation (C::DB only);
 // the caller keeps it consistent (see fft_next_par).
-template <class C, int S, int PAR = 0>
+template <class C, int S, int PAR = 0, int XP = 0>
 __device__ __forceinline__ void fft_in_regs(cf (&w)[C::P], const cf (&tw)[C::TW], cf *__restrict__ lds, int tid)
 {
-    run_pass<C, 0, S, PAR>(w, tw, lds, tid);
-    if constexpr (C::NPASS > 1) run_pass<C, 1, S, PAR>(w, tw, lds, tid);
-    if constexpr (C::NPASS > 2) run_pass<C, 2, S, PAR>(w, tw, lds, tid);
-    if constexpr (C::NPASS > 3) run_pass<C, 3, S, PAR>(w, tw, lds, tid);
+    run_pass<C, 0, S, PAR, XP>(w, tw, lds, tid);
+    if constexpr (C::NPASS > 1) run_pass<C, 1, S, PAR, XP>(w, tw, lds, tid);
+    if constexpr (C::NPASS > 2) run_pass<C, 2, S, PAR, XP>(w, tw, lds, tid);
+    if constexpr (C::NPASS > 3) run_pass<C, 3, S, PAR, XP>(w, tw, lds, tid);
 }
 template <class C> constexpr int fft_next_par(int par) { return (par + C::NPASS - 1) & 1; }
 

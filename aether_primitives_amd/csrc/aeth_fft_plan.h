@@ -30,6 +30,14 @@ struct aeth_fft {
     float2 *blu_filt = nullptr;      // FFT_m of the zero-padded conjugate chirp, / m
 };
 
+// overlap-save FIR plan (aeth_fir.hip)
+struct aeth_fir {
+    aeth_ctx *ctx = nullptr;
+    size_t ntaps = 0, fft_len = 0, hop = 0;
+    aeth_fft *fft = nullptr;      // owns the twiddle table; used once to transform the taps
+    float2 *Hf = nullptr;         // fwd(taps || 0) / N  (1/N folded in: exact, N is a power of two)
+};
+
 namespace aeth {
 
 enum { FFT_ALGO_POW2 = 1, FFT_ALGO_MIXED = 2, FFT_ALGO_FOURSTEP = 3, FFT_ALGO_BLUESTEIN = 4, FFT_ALGO_RAGGED = 5, FFT_ALGO_FOURSTEP_MIXED = 6 };

@@ -23,7 +23,7 @@ int launch_ragged(const aeth_fft *plan, const float2 *in, float2 *out, size_t ba
     const size_t cap = (size_t)ctx->num_cus * (LANES_PER_CU / C::WG);      // persistent grid
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
-#define AETH_FFT_RAGGED(SS, NN) hipLaunchKernelGGL((fft_ragged_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, ctx->stream, (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+#define AETH_FFT_RAGGED(SS, NN) hipLaunchKernelGGL((fft_ragged_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
     if (sign > 0) { if (nt) AETH_FFT_RAGGED(+1, true); else AETH_FFT_RAGGED(+1, false); }
     else          { if (nt) AETH_FFT_RAGGED(-1, true); else AETH_FFT_RAGGED(-1, false); }
 #undef AETH_FFT_RAGGED
@@ -35,10 +35,10 @@ template <class C>
 int build_ragged_table(aeth_fft *plan)
 {
     AETH_HIP(hipMalloc((void **)&plan->tw_lane_dev, (size_t)C::TW * C::T * sizeof(float2)));
-    hipLaunchKernelGGL((build_ragged_twiddles<C>), dim3(1), dim3((C::T + 63) / 64 * 64), 0, plan->ctx->stream,
+    hipLaunchKernelGGL((build_ragged_twiddles<C>), dim3(1), dim3((C::T + 63) / 64 * 64), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)plan->tw_dev, (cf *)plan->tw_lane_dev);
     AETH_HIP(hipGetLastError());
-    AETH_HIP(hipStreamSynchronize(plan->ctx->stream));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(plan->ctx)));
     return AETH_OK;
 }
 

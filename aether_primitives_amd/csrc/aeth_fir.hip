@@ -21,6 +21,7 @@
 #include "aeth_internal.h"
 #include "aeth_fft_core.h"
 #include "aeth_fft_plan.h"
+#include "aeth_fir_kernel.h"
 
 #include <cstdlib>
 #include <new>
@@ -28,228 +29,10 @@
 
 using namespace aeth::fftk;
 
-struct aeth_fir {
-    aeth_ctx *ctx = nullptr;
-    size_t ntaps = 0, fft_len = 0, hop = 0;
-    aeth_fft *fft = nullptr;      // owns the twiddle table; used once to transform the taps
-    float2 *Hf = nullptr;         // fwd(taps || 0) / N  (1/N folded in: exact, N is a power of two)
-};
+
+using namespace aeth::firk;
 
 namespace {
-
-struct FmiArgs {
-    const cf *in;
-    cf *out;
-    const cf *hist;       // ntaps-1 samples preceding in[0], or null
-    const cf *Hf;         // N spectrum multipliers, natural order
-    const cf *twN;
-    const cf *twL;        // per-lane twiddle table of the plan (null: gather from twN)
-    long long n;          // samples in `in` / outputs wanted
-    long long nblocks;
-    int hop, ov, nhist;
-    float s_fwd, s_bwd;
-    int dbg;              // tuning only (AETH_FIR_DBG): 4 = gather the twiddles instead of the per-lane table
-    // chirp-z (Bluestein) mode: a block is one frame of frame_n < N samples, multiplied by chirp[e] on the way in
-    // and on the way out, zero beyond frame_n; conj = transform with the other exponent sign
-    const cf *chirp = nullptr;
-    int frame_n = 0;      // valid samples per window (0: the whole window)
-    int conj = 0;
-};
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-// Stream accesses carry the non-temporal hint (aux bit 1) when the launch moves more than the cache holds: a
-// window is read once and an output block written once, so neither should displace the tables in L2 or take the
-// write-allocate path (A/B in one process on 256 MiB: stores alone -3 %, loads alone +3 %, both -5 % of the launch
-// time).  NT is a kernel template parameter: short chains over cache-sized operands (C4) keep plain accesses.
-
-__device__ __forceinline__ cf as_cf(u32x2 v) { return __builtin_bit_cast(cf, v); }
-__device__ __forceinline__ u32x2 as_u32x2(cf v) { return __builtin_bit_cast(u32x2, v); }
-
-// one block's input window -> registers (slot m = window element tid + m*T)
-template <class C, bool NT>
-__device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
-{
-    const long long win0 = blk * a.hop - a.ov;              // first input sample of the window
-    if (blk >= a.nblocks) {
-#pragma unroll
-        for (int m = 0; m < C::P; m++) x[m] = mk(0.f, 0.f);
-        return;
-    }
-    if constexpr (C::F == 1) {
-        if (win0 >= 0) {
-            // wave-uniform window: buffer loads, the descriptor's range check zero-fills past the end
-            long long left = a.n - win0;
-            int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;
-            auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
-#pragma unroll
-            for (int m = 0; m < C::P; m++)
-                x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
-            // (the window's oldest ov-nhist samples are zeroed when the window is consumed: doing it
-            // here would put a wait for the load right behind its issue)
-            return;
-        }
-    }
-    if constexpr (C::F > 1) {
-        // several windows per workgroup: when the whole group lies inside the stream (workgroup-uniform test)
-        // the loads need no per-element range logic, only the zeroing of the samples older than the history
-        const long long first = (blk - (long long)(threadIdx.x / C::T)) * a.hop - a.ov;
-        const long long last_end = first + (long long)(C::F - 1) * a.hop + C::N;
-        if (a.frame_n == C::N && first >= 0 && last_end <= a.n && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
-#pragma unroll
-            for (int m = 0; m < C::P; m++) {
-                const cf v = a.in[win0 + tid + m * C::T];
-                x[m] = (tid + m * C::T >= a.ov - a.nhist) ? v : mk(0.f, 0.f);
-            }
-            return;
-        }
-        if (a.frame_n < C::N && a.ov == 0 && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
-            // chirp-z frames (hop = frame_n samples each, zero beyond): every frame of the group exists
-#pragma unroll
-            for (int m = 0; m < C::P; m++) {
-                const int e = tid + m * C::T;
-                x[m] = e < a.frame_n ? a.in[win0 + e] : mk(0.f, 0.f);
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < C::P; m++) {
-        const long long gi = win0 + tid + m * C::T;
-        cf v = mk(0.f, 0.f);
-        if (tid + m * C::T >= a.ov - a.nhist && tid + m * C::T < a.frame_n) {
-            if (gi >= 0) { if (gi < a.n) v = a.in[gi]; }
-            else if (a.hist && gi >= -(long long)a.nhist) v = a.hist[a.nhist + gi];
-        }
-        x[m] = v;
-    }
-}
-
-// Branch-free form for the steady state of one-frame workgroups (win0 >= 0 guaranteed by
-// the caller): a block past the end gets a zero-length descriptor, so the loads still
-// issue -- and return zeros without touching memory.  No divergent path means hipcc can
-// COUNT the loads in flight (vmcnt(N)) instead of falling back to vmcnt(0).
-template <class C, bool NT>
-__device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
-{
-    const bool active = blk < a.nblocks;
-    const long long win0 = active ? blk * a.hop - a.ov : 0;
-    long long left = a.n - win0;
-    const int bytes = active ? (int)(left < a.frame_n ? left : a.frame_n) * 8 : 0;
-    auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
-#pragma unroll
-    for (int m = 0; m < C::P; m++)
-        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
-}
-
-template <class C, bool SCALED, bool NT>
-__device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
-{
-    if (blk >= a.nblocks) return;
-    const long long base = blk * a.hop - a.ov;              // output index of window element 0
-    if constexpr (C::F == 1) {
-        long long left = a.n - base;
-        int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;   // stores past the end (of the stream, of the frame) are dropped by the range check
-        auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + base, 0, bytes, 0x00020000);
-        const cf ss = mk(a.s_bwd, a.s_bwd);
-        // no branch around the stores either: window elements in front of the valid part
-        // (e < ov) get an offset past the descriptor's range and are dropped by its check
-#pragma unroll
-        for (int m = 0; m < C::P; m++) {
-            const int e = tid + m * C::T;
-            const int off = (e >= a.ov) ? e * 8 : 0x7ffffff0;
-            cf v = SCALED ? cscale_k(w[m], ss) : w[m];
-            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 18 : 0);   // nt + sc1: streamed stores (tools/nt_modes.hip: 6.55 vs 6.43 TB/s for nt alone)
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < C::P; m++) {
-            const int e = tid + m * C::T;
-            const long long o = base + e;
-            if (e >= a.ov && o < a.n && e < a.frame_n) a.out[o] = SCALED ? cscale(w[m], a.s_bwd) : w[m];
-        }
-    }
-}
-
-// SCALED = false: both Scale factors are 1 (FIR: 1/N is folded into H)
-// BLU: chirp-z frames (see FmiArgs): the frame is multiplied by the chirp behind the load and in front of the store
-template <class C, bool SCALED, int MINW, bool NT, bool BLU>
-__global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
-{
-    __shared__ cf lds_all[C::LDS_TOTAL];
-    // F == 1: the whole workgroup is one frame, so the block index stays provably wave-uniform
-    const int tid = (C::F == 1) ? (int)threadIdx.x : (int)(threadIdx.x % C::T);
-    const int fl = (C::F == 1) ? 0 : (int)(threadIdx.x / C::T);
-    cf *lds = lds_all + fl * C::LDS_FRAME;
-
-    const long long ngroups = (a.nblocks + C::F - 1) / C::F;
-    // software pipeline: the next block's window is in flight while this one is transformed.
-    // The first window goes out before the (L2-resident) tables so the HBM fetch starts at once.
-    cf nx[C::P];
-    load_window<C, NT>(nx, a, (long long)blockIdx.x * C::F + fl, tid);
-
-    cf tw[C::TW];
-    if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
-    else load_twiddles<C>(tw, a.twN, tid);
-    cf H[C::P];
-#pragma unroll
-    for (int m = 0; m < C::P; m++) H[m] = a.Hf[tid + m * C::T];
-    // Drain the table loads HERE, once.  Otherwise hipcc places their counted waits at the first
-    // uses inside the loop body, where they run every iteration and end in vmcnt(0) halfway
-    // through each block -- forcing the prefetched window AND the previous block's stores to
-    // complete there instead of riding under the whole block.
-    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only
-#pragma unroll 1
-    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const long long blk = g * C::F + fl;
-        cf w[C::P];
-#pragma unroll
-        for (int m = 0; m < C::P; m++) w[m] = nx[m];
-        // window samples older than the ntaps-1 the outputs depend on are forced to zero, so a
-        // block is a function of exactly x[out0-(ntaps-1) .. out0+hop): shards of one stream
-        // (history = ntaps-1 samples) then reproduce the unsharded run bit for bit
-        if constexpr (C::F == 1) { if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f); }
-        if constexpr (BLU) {
-            // x[n] (conjugated for the other exponent sign) * chirp[n]; chirp is 0 beyond the frame (descriptor range)
-            auto cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.chirp), 0, a.frame_n * 8, 0x00020000);
-#pragma unroll
-            for (int m = 0; m < C::P; m++) {
-                const cf ch = as_cf(__builtin_amdgcn_raw_buffer_load_b64(cr, (tid + m * C::T) * 8, 0, 0));
-                cf v = w[m];
-                if (a.conj) v.y = -v.y;
-                w[m] = cmul(v, ch);
-            }
-        }
-        const long long gn = g + gridDim.x;
-        if constexpr (C::F == 1) {
-            // gn >= gridDim.x >= 1, so the window never starts before the stream: descriptor path
-            load_window_srd<C, NT>(nx, a, gn, tid);
-        } else {
-            if (gn < ngroups) load_window<C, NT>(nx, a, gn * C::F + fl, tid);
-        }
-
-        fft_in_regs<C, +1, 0>(w, tw, lds, tid);             // vec_rfft: the reference's fwd (+j exponent)
-        if constexpr (SCALED) {
-            const cf ss = mk(a.s_fwd, a.s_fwd);
-#pragma unroll
-            for (int m = 0; m < C::P; m++) w[m] = cscale_k(w[m], ss);       // Scale of vec_rfft
-        }
-#pragma unroll
-        for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);             // vec_mul (vecops.rs:99-112)
-        fft_in_regs<C, -1, fft_next_par<C>(0)>(w, tw, lds, tid);   // vec_rifft: bwd (-j); two transforms leave the parity even
-        if constexpr (BLU) {
-            auto cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.chirp), 0, a.frame_n * 8, 0x00020000);
-#pragma unroll
-            for (int m = 0; m < C::P; m++) {
-                const cf ch = as_cf(__builtin_amdgcn_raw_buffer_load_b64(cr, (tid + m * C::T) * 8, 0, 0));
-                cf v = cmul(w[m], ch);
-                if (a.conj) v.y = -v.y;
-                w[m] = v;
-            }
-        }
-        store_block<C, SCALED, NT>(w, a, blk, tid);
-    }
-}
 
 template <class C, bool SCALED>
 int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
@@ -282,7 +65,7 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
 
 int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a, hipStream_t stream = nullptr)
 {
-    if (!stream) stream = ctx->stream;
+    if (!stream) stream = aeth::ctx_stream(ctx);
     aeth::DeviceGuard dev_guard(ctx->device);
     const bool scaled = a.chirp != nullptr || !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
 #define AETH_BODY(NN)                                                            \
@@ -390,7 +173,7 @@ int aeth_fir_destroy(aeth_fir *f)
 {
     if (!f) return AETH_OK;
     aeth::DeviceGuard g(f->ctx->device);
-    (void)hipStreamSynchronize(f->ctx->stream);
+    (void)hipStreamSynchronize(aeth::ctx_stream(f->ctx));
     if (f->Hf) (void)hipFree(f->Hf);
     if (f->fft) aeth_fft_destroy(f->fft);
     delete f;
@@ -415,7 +198,11 @@ int aeth_fir_exec(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_
     a.n = (long long)n; a.hop = (int)f->hop; a.ov = (int)(f->fft_len - f->hop); a.nhist = (int)(f->ntaps - 1);
     a.nblocks = (long long)((n + f->hop - 1) / f->hop);
     a.s_fwd = 1.0f; a.s_bwd = 1.0f;
-    return dispatch_fmi(f->ctx, f->fft_len, a);
+    // independent consecutive launches alternate between the context's two queues (aeth_ctx_set_overlap); a history
+    // buffer is usually the tail of something just written, so such calls stay on the in-order stream
+    hipStream_t lane = hist ? aeth::ctx_stream(f->ctx)
+                            : aeth::ctx_fir_lane(f->ctx, (uintptr_t)in, (uintptr_t)(in + n), (uintptr_t)out, (uintptr_t)(out + n));
+    return dispatch_fmi(f->ctx, f->fft_len, a, lane);
 }
 
 }  // extern "C"
@@ -478,7 +265,7 @@ int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *
         if ((e = hipMalloc((void **)&slot[s].dout, chunk * sizeof(float2))) != hipSuccess) { fail(e, "hipMalloc"); break; }
     }
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (rc == AETH_OK) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipStreamSynchronize(ctx->stream); (void)hipEventRecord(t0, slot[0].stream); }
+    if (rc == AETH_OK) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipStreamSynchronize(aeth::ctx_stream(ctx)); (void)hipEventRecord(t0, slot[0].stream); }
     for (size_t k = 0; k < nchunks && rc == AETH_OK; k++) {
         PipeSlot &sl = slot[k & 1];
         const size_t o0 = k * chunk;
@@ -528,12 +315,12 @@ int aeth_fir_exec_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, 
     rc = aeth::ctx_stage(ctx, 1, bytes); if (rc) return rc;
     float2 *dh = (float2 *)ctx->stage[0];
     float2 *din = dh + nh;     // nh*8 bytes in: keeps 8-byte alignment
-    if (hist && nh) AETH_HIP(hipMemcpyAsync(dh, hist, nh * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-    AETH_HIP(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (hist && nh) AETH_HIP(hipMemcpyAsync(dh, hist, nh * sizeof(float2), hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
     rc = aeth_fir_exec(f, hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)din, n, (aeth_cf32 *)ctx->stage[1]);
     if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(out, ctx->stage[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipMemcpyAsync(out, ctx->stage[1], bytes, hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 

@@ -1,0 +1,317 @@
+// aeth_fir_kernel.h -- device side of the fused  FFT -> (* H) -> IFFT  kernel (aeth_fir.hip holds the host side
+// and the reference citations; tools/fir_lab.hip instantiates the same template for A/B measurements).
+//
+// One 128-lane workgroup per overlap-save block (N = 2048: 16 points per lane), persistent loop over blocks,
+// the next block's window prefetched into registers while the current one is transformed.
+#pragma once
+
+#include "aeth_internal.h"
+#include "aeth_fft_core.h"
+
+namespace aeth {
+namespace firk {
+
+using namespace aeth::fftk;
+
+struct FmiArgs {
+    const cf *in;
+    cf *out;
+    const cf *hist;       // ntaps-1 samples preceding in[0], or null
+    const cf *Hf;         // N spectrum multipliers, natural order
+    const cf *twN;
+    const cf *twL;        // per-lane twiddle table of the plan (null: gather from twN)
+    long long n;          // samples in `in` / outputs wanted
+    long long nblocks;
+    int hop, ov, nhist;
+    float s_fwd, s_bwd;
+    int dbg;              // tuning only (AETH_FIR_DBG): 4 = gather the twiddles instead of the per-lane table
+    // chirp-z (Bluestein) mode: a block is one frame of frame_n < N samples, multiplied by chirp[e] on the way in
+    // and on the way out, zero beyond frame_n; conj = transform with the other exponent sign
+    const cf *chirp = nullptr;
+    int frame_n = 0;      // valid samples per window (0: the whole window)
+    int conj = 0;
+};
+
+// Kernel variants (template parameter VAR, a bit set).  0 is the round-1 kernel.
+enum : int {
+    V_PEEL  = 1,    // first block peeled out of the loop: window 0 is waited for alone (counted vmcnt), the tables
+                    // and window 1 land under the first transform instead of in front of it
+    V_TOUCH = 2,    // one 4-byte load per 128-byte line of the window two rounds ahead: pulls it into L2 / the
+                    // Infinity Cache so that the register prefetch one round later is served on-die
+    V_PRIO  = 4,    // s_setprio 1 around every LDS exchange (its latency chain is what a block's time is made of)
+    V_TOUCH3 = 8,   // with V_TOUCH: three rounds ahead instead of two
+    V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
+    V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
+    V_CENSUS = 256, // diagnosis only: every wave records HW_ID / XCC_ID in the buffer passed as `chirp`
+    V_NOLDS = 128,  // diagnosis only (wrong output): no LDS exchanges at all
+    V_NOBAR = 64,   // diagnosis only (wrong output): LDS exchanges without workgroup barriers
+};
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Stream accesses carry the non-temporal hint (aux bit 1) when the launch moves more than the cache holds: a
+// window is read once and an output block written once, so neither should displace the tables in L2 or take the
+// write-allocate path (A/B in one process on 256 MiB: stores alone -3 %, loads alone +3 %, both -5 % of the launch
+// time).  NT is a kernel template parameter: short chains over cache-sized operands (C4) keep plain accesses.
+
+__device__ __forceinline__ cf as_cf(u32x2 v) { return __builtin_bit_cast(cf, v); }
+__device__ __forceinline__ u32x2 as_u32x2(cf v) { return __builtin_bit_cast(u32x2, v); }
+
+// one block's input window -> registers (slot m = window element tid + m*T)
+template <class C, bool NT>
+__device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
+{
+    const long long win0 = blk * a.hop - a.ov;              // first input sample of the window
+    if (blk >= a.nblocks) {
+#pragma unroll
+        for (int m = 0; m < C::P; m++) x[m] = mk(0.f, 0.f);
+        return;
+    }
+    if constexpr (C::F == 1) {
+        if (win0 >= 0) {
+            // wave-uniform window: buffer loads, the descriptor's range check zero-fills past the end
+            long long left = a.n - win0;
+            int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;
+            auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < C::P; m++)
+                x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
+            // (the window's oldest ov-nhist samples are zeroed when the window is consumed: doing it
+            // here would put a wait for the load right behind its issue)
+            return;
+        }
+    }
+    if constexpr (C::F > 1) {
+        // several windows per workgroup: when the whole group lies inside the stream (workgroup-uniform test)
+        // the loads need no per-element range logic, only the zeroing of the samples older than the history
+        const long long first = (blk - (long long)(threadIdx.x / C::T)) * a.hop - a.ov;
+        const long long last_end = first + (long long)(C::F - 1) * a.hop + C::N;
+        if (a.frame_n == C::N && first >= 0 && last_end <= a.n && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
+#pragma unroll
+            for (int m = 0; m < C::P; m++) {
+                const cf v = a.in[win0 + tid + m * C::T];
+                x[m] = (tid + m * C::T >= a.ov - a.nhist) ? v : mk(0.f, 0.f);
+            }
+            return;
+        }
+        if (a.frame_n < C::N && a.ov == 0 && blk - (long long)(threadIdx.x / C::T) + C::F <= a.nblocks) {
+            // chirp-z frames (hop = frame_n samples each, zero beyond): every frame of the group exists
+#pragma unroll
+            for (int m = 0; m < C::P; m++) {
+                const int e = tid + m * C::T;
+                x[m] = e < a.frame_n ? a.in[win0 + e] : mk(0.f, 0.f);
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < C::P; m++) {
+        const long long gi = win0 + tid + m * C::T;
+        cf v = mk(0.f, 0.f);
+        if (tid + m * C::T >= a.ov - a.nhist && tid + m * C::T < a.frame_n) {
+            if (gi >= 0) { if (gi < a.n) v = a.in[gi]; }
+            else if (a.hist && gi >= -(long long)a.nhist) v = a.hist[a.nhist + gi];
+        }
+        x[m] = v;
+    }
+}
+
+// Branch-free form for the steady state of one-frame workgroups (win0 >= 0 guaranteed by
+// the caller): a block past the end gets a zero-length descriptor, so the loads still
+// issue -- and return zeros without touching memory.  No divergent path means hipcc can
+// COUNT the loads in flight (vmcnt(N)) instead of falling back to vmcnt(0).
+template <class C, bool NT>
+__device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
+{
+    const bool active = blk < a.nblocks;
+    const long long win0 = active ? blk * a.hop - a.ov : 0;
+    long long left = a.n - win0;
+    const int bytes = active ? (int)(left < a.frame_n ? left : a.frame_n) * 8 : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < C::P; m++)
+        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
+}
+
+// V_TOUCH: one dword per 128-byte line of block `blk`'s window (plain cache policy: the line is meant to stay on
+// the die until the register prefetch reads it); the value is never used, the caller only keeps it alive.
+template <class C>
+__device__ __forceinline__ unsigned touch_window(const FmiArgs &a, long long blk, int tid)
+{
+    const bool active = blk < a.nblocks;
+    const long long win0 = active ? blk * a.hop - a.ov : 0;
+    long long left = a.n - win0;
+    const int bytes = active ? (int)(left < a.frame_n ? left : a.frame_n) * 8 : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
+    unsigned acc = 0;
+#pragma unroll
+    for (int off = 0; off < C::N * 8; off += C::T * 128)
+        acc |= __builtin_amdgcn_raw_buffer_load_b32(rs, off + tid * 128, 0, 0);
+    return acc;
+}
+
+// CHECK = false: the caller knows that the block exists (no branch around the stores, so that hipcc keeps
+// counting the memory operations in flight across them)
+template <class C, bool SCALED, bool NT, bool CHECK = true>
+__device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
+{
+    if constexpr (CHECK) { if (blk >= a.nblocks) return; }
+    const long long base = blk * a.hop - a.ov;              // output index of window element 0
+    if constexpr (C::F == 1) {
+        long long left = a.n - base;
+        int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;   // stores past the end (of the stream, of the frame) are dropped by the range check
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + base, 0, bytes, 0x00020000);
+        const cf ss = mk(a.s_bwd, a.s_bwd);
+        // no branch around the stores either: window elements in front of the valid part
+        // (e < ov) get an offset past the descriptor's range and are dropped by its check
+#pragma unroll
+        for (int m = 0; m < C::P; m++) {
+            const int e = tid + m * C::T;
+            const int off = (e >= a.ov) ? e * 8 : 0x7ffffff0;
+            cf v = SCALED ? cscale_k(w[m], ss) : w[m];
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 18 : 0);   // nt + sc1: streamed stores (tools/nt_modes.hip: 6.55 vs 6.43 TB/s for nt alone)
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < C::P; m++) {
+            const int e = tid + m * C::T;
+            const long long o = base + e;
+            if (e >= a.ov && o < a.n && e < a.frame_n) a.out[o] = SCALED ? cscale(w[m], a.s_bwd) : w[m];
+        }
+    }
+}
+
+// the chain on one block held in w[]: vec_rfft -> vec_mul -> vec_rifft (benches/benches.rs:410-416)
+template <class C, bool SCALED, bool BLU, int VAR>
+__device__ __forceinline__ void transform_block(cf (&w)[C::P], const cf (&tw)[C::TW], const cf (&H)[C::P],
+                                                cf *__restrict__ lds, const FmiArgs &a, int tid)
+{
+    constexpr int XP = ((VAR & V_PRIO) ? 1 : 0) | ((VAR & V_NOBAR) ? 2 : 0) | ((VAR & V_NOLDS) ? 4 : 0);
+    if constexpr (BLU) {
+        // x[n] (conjugated for the other exponent sign) * chirp[n]; chirp is 0 beyond the frame (descriptor range)
+        auto cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.chirp), 0, a.frame_n * 8, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < C::P; m++) {
+            const cf ch = as_cf(__builtin_amdgcn_raw_buffer_load_b64(cr, (tid + m * C::T) * 8, 0, 0));
+            cf v = w[m];
+            if (a.conj) v.y = -v.y;
+            w[m] = cmul(v, ch);
+        }
+    }
+    fft_in_regs<C, +1, 0, XP>(w, tw, lds, tid);             // vec_rfft: the reference's fwd (+j exponent)
+    if constexpr (SCALED) {
+        const cf ss = mk(a.s_fwd, a.s_fwd);
+#pragma unroll
+        for (int m = 0; m < C::P; m++) w[m] = cscale_k(w[m], ss);           // Scale of vec_rfft
+    }
+#pragma unroll
+    for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);                 // vec_mul (vecops.rs:99-112)
+    fft_in_regs<C, -1, fft_next_par<C>(0), XP>(w, tw, lds, tid);   // vec_rifft: bwd (-j); two transforms leave the parity even
+    if constexpr (BLU) {
+        auto cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.chirp), 0, a.frame_n * 8, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < C::P; m++) {
+            const cf ch = as_cf(__builtin_amdgcn_raw_buffer_load_b64(cr, (tid + m * C::T) * 8, 0, 0));
+            cf v = cmul(w[m], ch);
+            if (a.conj) v.y = -v.y;
+            w[m] = v;
+        }
+    }
+}
+
+// SCALED = false: both Scale factors are 1 (FIR: 1/N is folded into H)
+// BLU: chirp-z frames (see FmiArgs): the frame is multiplied by the chirp behind the load and in front of the store
+template <class C, bool SCALED, int MINW, bool NT, bool BLU, int VAR = 0>
+__global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
+{
+    __shared__ cf lds_all[C::LDS_TOTAL];
+    // F == 1: the whole workgroup is one frame, so the block index stays provably wave-uniform
+    const int tid = (C::F == 1) ? (int)threadIdx.x : (int)(threadIdx.x % C::T);
+    const int fl = (C::F == 1) ? 0 : (int)(threadIdx.x / C::T);
+    cf *lds = lds_all + fl * C::LDS_FRAME;
+
+    if constexpr (VAR & V_CENSUS) {
+        if ((threadIdx.x & 63) == 0) {
+            unsigned *cb = reinterpret_cast<unsigned *>(const_cast<cf *>(a.chirp));
+            const unsigned slot = blockIdx.x * (C::WG / 64) + threadIdx.x / 64;
+            cb[2 * slot] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+            cb[2 * slot + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+        }
+    }
+    const long long ngroups = (a.nblocks + C::F - 1) / C::F;
+    constexpr bool PEEL = (VAR & V_PEEL) && C::F == 1 && !BLU;
+    constexpr bool TOUCH = (VAR & V_TOUCH) && C::F == 1 && !BLU;
+    constexpr int TOUCH_AHEAD = (VAR & V_TOUCH3) ? 3 : 2;
+    cf nx[C::P], tw[C::TW], H[C::P];
+    long long g0 = blockIdx.x;
+    unsigned tprev = 0;     // V_TOUCH: the previous round's touch result, kept alive until the next round (never used)
+
+    if constexpr (PEEL) {
+        // Block 0 of this workgroup outside the loop.  Issue order = return order: window 0, tables, window 1.  The
+        // first pass needs window 0 only, so its wait leaves the tables and the next window in flight; they land
+        // while pass 0 and the first exchange run.
+        cf w[C::P];
+        if (blockIdx.x == 0) load_window<C, NT>(w, a, 0, tid);     // history / zero initial state: predicated path
+        else load_window_srd<C, NT>(w, a, g0, tid);
+        if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
+        else load_twiddles<C>(tw, a.twN, tid);
+#pragma unroll
+        for (int m = 0; m < C::P; m++) H[m] = a.Hf[tid + m * C::T];
+        load_window_srd<C, NT>(nx, a, g0 + gridDim.x, tid);
+        if constexpr (TOUCH) {
+#pragma unroll
+            for (int k = 2; k <= TOUCH_AHEAD; k++) tprev |= touch_window<C>(a, g0 + (long long)k * gridDim.x, tid);
+        }
+        if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f);
+        transform_block<C, SCALED, BLU, VAR>(w, tw, H, lds, a, tid);
+        store_block<C, SCALED, NT, false>(w, a, g0, tid);          // grid <= ngroups: the block exists
+        g0 += gridDim.x;
+    } else {
+        // software pipeline: the next block's window is in flight while this one is transformed.
+        // The first window goes out before the (L2-resident) tables so the HBM fetch starts at once.
+        load_window<C, NT>(nx, a, (long long)blockIdx.x * C::F + fl, tid);
+        if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
+        else load_twiddles<C>(tw, a.twN, tid);
+#pragma unroll
+        for (int m = 0; m < C::P; m++) H[m] = a.Hf[tid + m * C::T];
+        // Drain the table loads HERE, once.  Otherwise hipcc places their counted waits at the first
+        // uses inside the loop body, where they run every iteration and end in vmcnt(0) halfway
+        // through each block -- forcing the prefetched window AND the previous block's stores to
+        // complete there instead of riding under the whole block.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only
+    }
+#pragma unroll 1
+    for (long long g = g0; g < ngroups; g += gridDim.x) {
+        const long long blk = g * C::F + fl;
+        cf w[C::P];
+#pragma unroll
+        for (int m = 0; m < C::P; m++) w[m] = nx[m];
+        // window samples older than the ntaps-1 the outputs depend on are forced to zero, so a
+        // block is a function of exactly x[out0-(ntaps-1) .. out0+hop): shards of one stream
+        // (history = ntaps-1 samples) then reproduce the unsharded run bit for bit
+        if constexpr (C::F == 1) { if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f); }
+        const long long gn = g + gridDim.x;
+        if constexpr (VAR & V_NOLOAD) {
+#pragma unroll
+            for (int m = 0; m < C::P; m++) asm volatile("" : "+v"(nx[m]));     // opaque, so that nothing folds
+        } else if constexpr (C::F == 1) {
+            // gn >= gridDim.x >= 1, so the window never starts before the stream: descriptor path
+            load_window_srd<C, NT>(nx, a, gn, tid);
+        } else {
+            if (gn < ngroups) load_window<C, NT>(nx, a, gn * C::F + fl, tid);
+        }
+        if constexpr (TOUCH) {
+            asm volatile("" ::"v"(tprev));      // issued a whole round ago: no wait
+            tprev = touch_window<C>(a, g + (long long)TOUCH_AHEAD * gridDim.x, tid);
+        }
+        transform_block<C, SCALED, BLU, VAR>(w, tw, H, lds, a, tid);
+        if constexpr (VAR & V_NOSTORE) {
+#pragma unroll
+            for (int m = 0; m < C::P; m++) asm volatile("" ::"v"(w[m]));
+        } else store_block<C, SCALED, NT>(w, a, blk, tid);
+    }
+    if constexpr (TOUCH) asm volatile("" ::"v"(tprev));
+}
+
+}  // namespace firk
+}  // namespace aeth

@@ -12,9 +12,21 @@
 
 struct aeth_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream_main = nullptr;   // use aeth::ctx_stream(ctx): it orders the caller behind the overlap lane
     bool owns_stream = false;
     int num_cus = 256;
+    // Overlap lane (aeth_ctx_set_overlap): a second HIP queue.  Consecutive fused-FIR launches whose buffers do not
+    // touch each other alternate between the two queues, so that the drain of one launch (its last round only
+    // stores) runs beside the fill of the next (its first round only loads).  Every launch is ordered behind
+    // everything except its immediate predecessor; any other call on the context joins the lane first, so
+    // results are those of one in-order stream.
+    hipStream_t stream_aux = nullptr;
+    hipEvent_t ev_pre[2] = {nullptr, nullptr};   // [lane] recorded on that lane right before its latest FIR launch
+    hipEvent_t ev_aux_done = nullptr;
+    bool overlap = false;          // feature switch (off for borrowed streams)
+    bool aux_pending = false;      // the aux lane holds work the main stream is not yet ordered behind
+    int chain_last = -1;           // lane of the latest FIR launch while nothing else has been enqueued since; else -1
+    uintptr_t last_in[2] = {0, 0}, last_out[2] = {0, 0};   // [lo, hi) byte ranges of that launch
     // staging for the host-slice flavours: pinned host + device scratch, grown on demand
     void *pin[2] = {nullptr, nullptr};
     size_t pin_bytes[2] = {0, 0};
@@ -26,6 +38,14 @@ namespace aeth {
 
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int hip_fail(hipError_t e, const char *what);
+
+// The context's stream for anything but a chained FIR launch: joins the overlap lane (the main stream waits for
+// what the aux lane still holds) and ends the chain.
+hipStream_t ctx_stream(aeth_ctx *ctx);
+inline hipStream_t ctx_stream(const aeth_ctx *ctx) { return ctx_stream(const_cast<aeth_ctx *>(ctx)); }
+// Stream for a fused-FIR launch reading [in_lo, in_hi) and writing [out_lo, out_hi): the other lane when the
+// previous call on this context was such a launch and the buffers are disjoint, else the main stream.
+hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintptr_t out_lo, uintptr_t out_hi);
 
 // ensure staging slot `i` holds >= bytes (device + pinned host)
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes);

@@ -132,8 +132,8 @@ int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, con
     const bool nt = aeth::streams_past_cache(n_out * sizeof(float2));
 #define AETH_MOD(B, V, G)                                                                                                 \
     do {                                                                                                                  \
-        if (nt) hipLaunchKernelGGL((modulate_kernel<B, V, true>), G, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);   \
-        else hipLaunchKernelGGL((modulate_kernel<B, V, false>), G, b, 0, ctx->stream, bits, (float2 *)out, n_out, t);     \
+        if (nt) hipLaunchKernelGGL((modulate_kernel<B, V, true>), G, b, 0, aeth::ctx_stream(ctx), bits, (float2 *)out, n_out, t);   \
+        else hipLaunchKernelGGL((modulate_kernel<B, V, false>), G, b, 0, aeth::ctx_stream(ctx), bits, (float2 *)out, n_out, t);     \
     } while (0)
     if (bps == 1 && vec) AETH_MOD(1, true, gv);
     else if (bps == 1)   AETH_MOD(1, false, gs);
@@ -161,8 +161,8 @@ int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym, size_t nsym, int bps, 
     const bool nt = aeth::streams_past_cache(nsym * sizeof(float2));
 #define AETH_DEM(B, V, G)                                                                                                         \
     do {                                                                                                                          \
-        if (nt) hipLaunchKernelGGL((demod_kernel<B, V, true>), G, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);  \
-        else hipLaunchKernelGGL((demod_kernel<B, V, false>), G, b, 0, ctx->stream, (const float2 *)sym, bits, nsym, t, compat);    \
+        if (nt) hipLaunchKernelGGL((demod_kernel<B, V, true>), G, b, 0, aeth::ctx_stream(ctx), (const float2 *)sym, bits, nsym, t, compat);  \
+        else hipLaunchKernelGGL((demod_kernel<B, V, false>), G, b, 0, aeth::ctx_stream(ctx), (const float2 *)sym, bits, nsym, t, compat);    \
     } while (0)
     if (bps == 1 && vec) AETH_DEM(1, true, gv);
     else if (bps == 1)   AETH_DEM(1, false, gs);

@@ -73,7 +73,7 @@ int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal, size_t n, float power, uin
     aeth::DeviceGuard dev_guard(ctx->device);
     const size_t pairs = (n + 1) / 2;
     auto kern = aeth::streams_past_cache(2 * n * sizeof(float2)) ? awgn_apply_kernel<true> : awgn_apply_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
                        reinterpret_cast<float2 *>(signal), n, scale, seed, offset, aeth::aligned16(signal) ? 1 : 0);
     AETH_HIP(hipGetLastError());
     return AETH_OK;

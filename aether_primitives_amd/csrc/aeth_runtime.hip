@@ -36,6 +36,59 @@ int tuning_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+hipStream_t ctx_stream(aeth_ctx *ctx)
+{
+    if (ctx->aux_pending) {
+        DeviceGuard g(ctx->device);
+        // the main stream continues behind everything the aux lane holds
+        if (hipEventRecord(ctx->ev_aux_done, ctx->stream_aux) == hipSuccess)
+            (void)hipStreamWaitEvent(ctx->stream_main, ctx->ev_aux_done, 0);
+        else (void)hipStreamSynchronize(ctx->stream_aux);
+        ctx->aux_pending = false;
+    }
+    ctx->chain_last = -1;
+    return ctx->stream_main;
+}
+
+static inline bool ranges_touch(uintptr_t a_lo, uintptr_t a_hi, uintptr_t b_lo, uintptr_t b_hi)
+{
+    return a_lo < b_hi && b_lo < a_hi;
+}
+
+hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintptr_t out_lo, uintptr_t out_hi)
+{
+    if (!ctx->overlap) return ctx_stream(ctx);
+    const int prev = ctx->chain_last;
+    bool chained = prev >= 0;
+    if (chained) {
+        // the only launch this one is NOT ordered behind is its immediate predecessor: their buffers must be disjoint
+        const uintptr_t *pi = ctx->last_in, *po = ctx->last_out;
+        if (ranges_touch(in_lo, in_hi, po[0], po[1]) || ranges_touch(out_lo, out_hi, pi[0], pi[1]) ||
+            ranges_touch(out_lo, out_hi, po[0], po[1]))
+            chained = false;
+    }
+    int lane = 0;
+    hipStream_t s;
+    if (!chained) {
+        s = ctx_stream(ctx);                    // joins; everything enqueued so far is in front of this launch
+    } else {
+        lane = 1 - prev;
+        s = lane ? ctx->stream_aux : ctx->stream_main;
+        // behind everything the other lane held BEFORE its latest launch (which itself runs beside this one)
+        if (hipStreamWaitEvent(s, ctx->ev_pre[prev], 0) != hipSuccess) { s = ctx_stream(ctx); lane = 0; }
+    }
+    if (hipEventRecord(ctx->ev_pre[lane], s) != hipSuccess) {   // this lane's history in front of the launch
+        s = ctx_stream(ctx); lane = 0;
+        ctx->chain_last = -1;                   // no chain without the event
+        return s;
+    }
+    if (lane == 1) ctx->aux_pending = true;
+    ctx->chain_last = lane;
+    ctx->last_in[0] = in_lo; ctx->last_in[1] = in_hi;
+    ctx->last_out[0] = out_lo; ctx->last_out[1] = out_hi;
+    return s;
+}
+
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes)
 {
     DeviceGuard dev_guard(ctx->device);
@@ -82,7 +135,8 @@ static int ctx_make(int device, hipStream_t borrowed, bool borrow, aeth_ctx **ou
     int n = 0;
     AETH_HIP(hipGetDeviceCount(&n));
     AETH_REQUIRE(device >= 0 && device < n, AETH_E_ARG, "device %d out of range (have %d)", device, n);
-    AETH_HIP(hipSetDevice(device));
+    aeth::DeviceGuard dev_guard(device);        // the caller's current device is restored on return
+    AETH_REQUIRE(dev_guard.ok, AETH_E_HIP, "hipSetDevice(%d) failed", device);
     aeth_ctx *c = new (std::nothrow) aeth_ctx();
     AETH_REQUIRE(c, AETH_E_NOMEM, "out of host memory");
     c->device = device;
@@ -90,16 +144,46 @@ static int ctx_make(int device, hipStream_t borrowed, bool borrow, aeth_ctx **ou
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->num_cus = prop.multiProcessorCount;
     if (borrow) {
-        c->stream = borrowed;
+        c->stream_main = borrowed;
         c->owns_stream = false;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        hipError_t e = hipStreamCreateWithFlags(&c->stream_main, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return aeth::hip_fail(e, "hipStreamCreateWithFlags"); }
         c->owns_stream = true;
     }
     *out = c;
     return AETH_OK;
 }
+
+static void overlap_release(aeth_ctx *c)
+{
+    if (c->stream_aux) { (void)hipStreamSynchronize(c->stream_aux); (void)hipStreamDestroy(c->stream_aux); c->stream_aux = nullptr; }
+    for (int i = 0; i < 2; i++) if (c->ev_pre[i]) { (void)hipEventDestroy(c->ev_pre[i]); c->ev_pre[i] = nullptr; }
+    if (c->ev_aux_done) { (void)hipEventDestroy(c->ev_aux_done); c->ev_aux_done = nullptr; }
+    c->overlap = false; c->aux_pending = false; c->chain_last = -1;
+}
+
+int aeth_ctx_set_overlap(aeth_ctx *ctx, int enable)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    aeth::DeviceGuard g(ctx->device);
+    (void)aeth::ctx_stream(ctx);                 // join whatever is in flight
+    if (!enable) {
+        if (ctx->stream_aux) { AETH_HIP(hipStreamSynchronize(ctx->stream_main)); overlap_release(ctx); }
+        return AETH_OK;
+    }
+    // a borrowed stream receives work this library does not see, so nothing can be reordered around it
+    AETH_REQUIRE(ctx->owns_stream, AETH_E_UNSUPPORTED, "overlap needs a context that owns its stream");
+    if (ctx->overlap) return AETH_OK;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_pre[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_aux_done, hipEventDisableTiming);
+    if (e != hipSuccess) { overlap_release(ctx); return aeth::hip_fail(e, "overlap lane set-up"); }
+    ctx->overlap = true;
+    return AETH_OK;
+}
+
+int aeth_ctx_overlap(const aeth_ctx *ctx) { return ctx && ctx->overlap ? 1 : 0; }
 
 int aeth_ctx_create(int device, aeth_ctx **out) { return ctx_make(device, nullptr, false, out); }
 
@@ -112,12 +196,13 @@ int aeth_ctx_destroy(aeth_ctx *ctx)
 {
     if (!ctx) return AETH_OK;
     aeth::DeviceGuard g(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(aeth::ctx_stream(ctx));
+    overlap_release(ctx);
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
     }
-    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->owns_stream && ctx->stream_main) (void)hipStreamDestroy(ctx->stream_main);
     delete ctx;
     return AETH_OK;
 }
@@ -125,11 +210,14 @@ int aeth_ctx_destroy(aeth_ctx *ctx)
 int aeth_ctx_sync(aeth_ctx *ctx)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    aeth::DeviceGuard g(ctx->device);
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));       // the join puts the aux lane in front of this wait
     return AETH_OK;
 }
 
-void *aeth_ctx_stream(aeth_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+/* hands the stream to code this library does not see: joined first, and the overlap lane stays out of the way
+ * only as long as every later call comes through the library again */
+void *aeth_ctx_stream(aeth_ctx *ctx) { return ctx ? (void *)aeth::ctx_stream(ctx) : nullptr; }
 int aeth_ctx_device(const aeth_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 int aeth_dev_alloc(aeth_ctx *ctx, size_t bytes, void **dptr)
@@ -146,7 +234,7 @@ int aeth_dev_free(aeth_ctx *ctx, void *dptr)
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
     if (!dptr) return AETH_OK;
     aeth::DeviceGuard g(ctx->device);
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     AETH_HIP(hipFree(dptr));
     return AETH_OK;
 }
@@ -157,8 +245,8 @@ int aeth_upload(aeth_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes
     aeth::DeviceGuard dev_guard(ctx->device);
     if (bytes == 0) return AETH_OK;
     AETH_REQUIRE(dst_dev && src_host, AETH_E_ARG, "null pointer");
-    AETH_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 
@@ -168,8 +256,8 @@ int aeth_download(aeth_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
     aeth::DeviceGuard dev_guard(ctx->device);
     if (bytes == 0) return AETH_OK;
     AETH_REQUIRE(dst_host && src_dev, AETH_E_ARG, "null pointer");
-    AETH_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 
@@ -179,7 +267,7 @@ int aeth_copy_dev(aeth_ctx *ctx, void *dst_dev, const void *src_dev, size_t byte
     aeth::DeviceGuard dev_guard(ctx->device);
     if (bytes == 0) return AETH_OK;
     AETH_REQUIRE(dst_dev && src_dev, AETH_E_ARG, "null pointer");
-    AETH_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    AETH_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 
@@ -199,6 +287,7 @@ int aeth_event_create(aeth_ctx *ctx, aeth_event **out)
     aeth_event *e = new (std::nothrow) aeth_event();
     AETH_REQUIRE(e, AETH_E_NOMEM, "out of host memory");
     e->ctx = ctx;
+    aeth::DeviceGuard g(ctx->device);
     hipError_t r = hipEventCreate(&e->ev);
     if (r != hipSuccess) { delete e; return aeth::hip_fail(r, "hipEventCreate"); }
     *out = e;
@@ -216,7 +305,8 @@ int aeth_event_destroy(aeth_event *ev)
 int aeth_event_record(aeth_event *ev)
 {
     AETH_REQUIRE(ev, AETH_E_ARG, "event is null");
-    AETH_HIP(hipEventRecord(ev->ev, ev->ctx->stream));
+    aeth::DeviceGuard g(ev->ctx->device);
+    AETH_HIP(hipEventRecord(ev->ev, aeth::ctx_stream(ev->ctx)));   // behind both lanes
     return AETH_OK;
 }
 

@@ -147,11 +147,11 @@ int interpolate_impl(aeth_ctx *ctx, const aeth_cf32 *src, size_t S, size_t batch
         size_t slots = kOutPerWG / (nb + 1) + 2 * (kOutPerWG / Lo + 2) + 4;
         if (slots > (size_t)kOutPerWG + 4) slots = kOutPerWG + 4;
         auto k32 = aeth::streams_past_cache(total * sizeof(float2)) ? interpolate_kernel32<true> : interpolate_kernel32<false>;
-        hipLaunchKernelGGL(k32, g, b, slots * sizeof(float4), ctx->stream, reinterpret_cast<const float2 *>(src),
+        hipLaunchKernelGGL(k32, g, b, slots * sizeof(float4), aeth::ctx_stream(ctx), reinterpret_cast<const float2 *>(src),
                            reinterpret_cast<float2 *>(dst), (uint32_t)S, make_fastdiv((uint32_t)Lo), (uint32_t)total,
                            make_fastdiv((uint32_t)(nb + 1)), (float)(nb + 1), compat, wide);
     } else {
-        hipLaunchKernelGGL(interpolate_kernel64, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream,
+        hipLaunchKernelGGL(interpolate_kernel64, dim3(grid_for(ctx, total)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
                            reinterpret_cast<const float2 *>(src), reinterpret_cast<float2 *>(dst), S, Lo, total,
                            (unsigned)(nb + 1), (float)(nb + 1), compat);
     }
@@ -187,11 +187,11 @@ int aeth_host_interpolate(aeth_ctx *ctx, const aeth_cf32 *src, size_t n_src, aet
     AETH_REQUIRE(cap >= Lo, AETH_E_LEN, "dst capacity %zu < %zu", cap, Lo);
     int rc = aeth::ctx_stage(ctx, 0, n_src * sizeof(aeth_cf32)); if (rc) return rc;
     rc = aeth::ctx_stage(ctx, 1, Lo * sizeof(aeth_cf32)); if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(ctx->stage[0], src, n_src * sizeof(aeth_cf32), hipMemcpyHostToDevice, ctx->stream));
+    AETH_HIP(hipMemcpyAsync(ctx->stage[0], src, n_src * sizeof(aeth_cf32), hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
     rc = interpolate_impl(ctx, (const aeth_cf32 *)ctx->stage[0], n_src, 1, (aeth_cf32 *)ctx->stage[1], Lo, nb, compat, n_written);
     if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(dst, ctx->stage[1], Lo * sizeof(aeth_cf32), hipMemcpyDeviceToHost, ctx->stream));
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipMemcpyAsync(dst, ctx->stage[1], Lo * sizeof(aeth_cf32), hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 
@@ -211,8 +211,8 @@ int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, siz
     const bool nt = aeth::streams_past_cache(n_dst * elem * 2);
 #define AETH_DS(TT)                                                                                                       \
     do {                                                                                                                  \
-        if (nt) hipLaunchKernelGGL((downsample_kernel<TT, true>), g, b, 0, ctx->stream, (const TT *)src, (TT *)dst, n_dst, dec);  \
-        else hipLaunchKernelGGL((downsample_kernel<TT, false>), g, b, 0, ctx->stream, (const TT *)src, (TT *)dst, n_dst, dec);    \
+        if (nt) hipLaunchKernelGGL((downsample_kernel<TT, true>), g, b, 0, aeth::ctx_stream(ctx), (const TT *)src, (TT *)dst, n_dst, dec);  \
+        else hipLaunchKernelGGL((downsample_kernel<TT, false>), g, b, 0, aeth::ctx_stream(ctx), (const TT *)src, (TT *)dst, n_dst, dec);    \
     } while (0)
     switch (elem) {
     case 1:  AETH_DS(uint8_t); break;
@@ -234,11 +234,11 @@ int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
     int rc = aeth::ctx_stage(ctx, 0, n_src * elem); if (rc) return rc;
     rc = aeth::ctx_stage(ctx, 1, n_dst * elem); if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(ctx->stage[0], src, n_src * elem, hipMemcpyHostToDevice, ctx->stream));
+    AETH_HIP(hipMemcpyAsync(ctx->stage[0], src, n_src * elem, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
     rc = aeth_downsample(ctx, ctx->stage[0], n_src, ctx->stage[1], n_dst, elem);
     if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(dst, ctx->stage[1], n_dst * elem, hipMemcpyDeviceToHost, ctx->stream));
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipMemcpyAsync(dst, ctx->stage[1], n_dst * elem, hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 

@@ -86,8 +86,8 @@ int launch_ew(aeth_ctx *ctx, aeth_cf32 *self, const aeth_cf32 *other, size_t n, 
     const bool nt = aeth::streams_past_cache(n * sizeof(float2) * ((reads_self<OP>() ? 2 : 1) + (two ? 1 : 0)));
 #define AETH_EW(VV, GRID, A, B, N)                                                                                      \
     do {                                                                                                                \
-        if (nt) hipLaunchKernelGGL((ew_kernel<OP, VV, true>), GRID, dim3(kBlock), 0, ctx->stream, A, B, N, s);          \
-        else hipLaunchKernelGGL((ew_kernel<OP, VV, false>), GRID, dim3(kBlock), 0, ctx->stream, A, B, N, s);            \
+        if (nt) hipLaunchKernelGGL((ew_kernel<OP, VV, true>), GRID, dim3(kBlock), 0, aeth::ctx_stream(ctx), A, B, N, s);          \
+        else hipLaunchKernelGGL((ew_kernel<OP, VV, false>), GRID, dim3(kBlock), 0, aeth::ctx_stream(ctx), A, B, N, s);            \
     } while (0)
     if (ma == mb) {
         // same phase: peel one sample if the base sits on an odd 8-byte slot, then 16-byte body
@@ -133,12 +133,12 @@ int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch
     if (vec) {
         size_t total = batch * (mid / 2);
         auto k = nt ? mirror_kernel<float4, true> : mirror_kernel<float4, false>;
-        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream,
+        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
                            reinterpret_cast<float4 *>(x), frame_len / 2, mid / 2, batch);
     } else {
         size_t total = batch * mid;
         auto k = nt ? mirror_kernel<float2, true> : mirror_kernel<float2, false>;
-        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, x, frame_len, mid, batch);
+        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, aeth::ctx_stream(ctx), x, frame_len, mid, batch);
     }
     AETH_HIP(hipGetLastError());
     return AETH_OK;
@@ -172,12 +172,12 @@ int host_roundtrip(aeth_ctx *ctx, aeth_cf32 *self, size_t n, const aeth_cf32 *ot
     int rc = aeth::ctx_stage(ctx, 0, bytes);
     if (rc) return rc;
     if (other) { rc = aeth::ctx_stage(ctx, 1, bytes); if (rc) return rc; }
-    if (upload_self) AETH_HIP(hipMemcpyAsync(ctx->stage[0], self, bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (other) AETH_HIP(hipMemcpyAsync(ctx->stage[1], other, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (upload_self) AETH_HIP(hipMemcpyAsync(ctx->stage[0], self, bytes, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
+    if (other) AETH_HIP(hipMemcpyAsync(ctx->stage[1], other, bytes, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
     rc = run((aeth_cf32 *)ctx->stage[0], (const aeth_cf32 *)ctx->stage[1]);
     if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(self, ctx->stage[0], bytes, hipMemcpyDeviceToHost, ctx->stream));
-    AETH_HIP(hipStreamSynchronize(ctx->stream));
+    AETH_HIP(hipMemcpyAsync(self, ctx->stage[0], bytes, hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
 }
 

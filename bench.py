@@ -9,7 +9,7 @@ through a working set larger than the 256 MiB Infinity Cache so every step
 reads its input from HBM.  Frames are independent, so N GPUs run N
 independent streams (weak scaling, no collective on the data path).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own N ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -17,6 +17,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,29 +53,74 @@ def lowpass_taps(ntaps=NTAPS, cutoff=0.25):
     return (t / t.sum()).astype(np.complex64)
 
 
-def cpu_baseline(budget_s=12.0):
-    """Oracle (CPU restatement of the reference chain) on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=16.0):
+    """The CPU restatement of the reference chain (oracle/aeth_oracle.c: rfft -> vec_mul -> rifft per overlap-save
+    block, f32) on a bounded sample of the same workload, on this box's host cores: 1 thread (the reference's own
+    per-call path is single-threaded) and T = every core this process may run on.  Timed
+    on a `-O3 -march=native -ffp-contract=off` build made on this machine; the portable -O2 build if that fails."""
+    import ctypes as C
     from oracle import pyoracle as orc
     n = 1 << 22
     x = orc.synth_cnormal(815, n)
     taps = orc.synth_lowpass_taps(NTAPS, 0.25)
+    y = np.empty_like(x)
+    hop = FFT_LEN - NTAPS + 1 - ((FFT_LEN - NTAPS + 1) % 64)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 16)      # the GPU box's CPU share for one GPU
+    nat, flags = orc.native_fir_lib()
+    if nat is not None:
+        def run(th):
+            rc = nat.orc_fir_ols_f32_mt(taps.ctypes.data, taps.size, FFT_LEN, hop, x.ctypes.data, n, y.ctypes.data, th)
+            assert rc == 0
+    else:
+        flags = "-O2 -ffp-contract=off (portable build; " + flags + ")"
+        def run(th):
+            orc.fir_ols_f32(taps, x, FFT_LEN, hop, threads=th)
+    # T: every core this process may run on, unless fewer threads are faster (a GPU box hands one GPU's job a
+    # share of a big host: 256 visible hardware threads, far fewer schedulable at once) -- short sweep, best kept
+    cores = min(cores, 256)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    cands = sorted({c for c in (8, 16, 32, 64, 128, cores, quota or cores) if c and c <= cores})
+    best_t, best_r = cores, 0.0
+    run(cores)                                     # page the buffers in
+    for c in cands:
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < 1.0:
+            run(c); reps += 1
+        r = reps * n / (time.perf_counter() - t0)
+        if r > best_r:
+            best_t, best_r = c, r
     res = {}
-    for label, th in (("1", 1), ("T", cores)):
+    for label, th in (("1", 1), ("T", best_t)):
         done, t0 = 0, time.perf_counter()
         while True:
-            orc.fir_ols_f32(taps, x, FFT_LEN, FFT_LEN - NTAPS + 1 - ((FFT_LEN - NTAPS + 1) % 64), threads=th)
+            run(th)
             done += n
             el = time.perf_counter() - t0
             if el >= budget_s / 2:
                 break
         res[label] = done / el / 1e9
         res[label + "_n"] = done
-    return {"value": round(res["T"], 5), "unit": "GSamples/s", "cores": cores, "kind": "port",
-            "value_1thread": round(res["1"], 5),
+    return {"value": round(res["T"], 5), "unit": "GSamples/s", "cores": best_t, "kind": "port",
+            "value_1thread": round(res["1"], 5), "cpu_model": cpu_model(), "cores_visible": cores,
+            "cgroup_cpu_quota": quota, "threads_tried": cands, "build": "gcc " + flags,
             "sample": f"oracle/aeth_oracle.c overlap-save chain (rfft->vec_mul->rifft, f32) over "
-                      f"{res['T_n'] >> 20} Mi samples on {cores} threads / {res['1_n'] >> 20} Mi on 1 thread, "
+                      f"{res['T_n'] >> 20} Mi samples on {best_t} threads / {res['1_n'] >> 20} Mi on 1 thread, "
                       f"same taps and FFT-2048 geometry as the GPU run"}
 
 
@@ -102,11 +149,9 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
-            # the process count is the truth (for N > 1 launch through
-            # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`)
-            if self.rank == 0 and args.gpus != 1:
-                print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; reporting n_gpus={self.world}", file=sys.stderr)
-            args.gpus = self.world
+            # never report a line whose n_gpus is not the number of ranks that ran
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch "
+                             f"`python bench.py --gpus {args.gpus}` (it starts its own ranks) or pass --gpus {self.world}")
         import torch
         self.torch = torch
         self.dist = None
@@ -123,6 +168,14 @@ class Ranks:
             self.dist.all_reduce(t)
         self.torch.cuda.synchronize()
         ctx.sync()
+
+    def ranks_seen(self):
+        """Number of ranks the collective backend actually spans (the line's n_gpus must equal it)."""
+        if self.dist is None:
+            return 1
+        t = self.torch.ones(1, device="cuda")
+        self.dist.all_reduce(t)
+        return int(round(float(t.item())))
 
     def max_over_ranks(self, seconds):
         if self.dist is None:
@@ -151,57 +204,88 @@ def settle(step, ctx, ms):
 
 def side_workload(args):
     """BASELINE configs 2, 4 and 5 (device-resident, synthetic); same JSON shape, no roofline claim.
-    Under torch.distributed.run every rank runs its own channel (C4) / frame shard (C2, C5) on its own GPU."""
+    C4 and C5 are the node-level jobs BASELINE.json names, partitioned with aether_primitives_amd.sharding (the
+    helpers tests/test_dist_shard.py validates): C4 = 8 independent channels, channel c on rank c % N; C5 = 512
+    frames of 65536 samples, contiguous frame ranges -- fixed total work, so "scaling" is strong.  C2 is one
+    cache-resident 1 Mi-sample stream per rank (weak)."""
     ranks = Ranks(args)
     import aether_primitives_amd as ap
     from aether_primitives_amd import Scale, sampling, modulation, noise
+    from aether_primitives_amd.sharding import channel_of, frame_shard
     ctx = ap.Context(ranks.local_rank)
     N = 2048
+    scaling = "strong"
     if args.workload == "c2":
+        scaling = "weak"
         n = 1 << 20                                             # 512 frames: 8 MiB, cache-resident by definition
         f = ap.HipFft(ctx, N, max_batch=n // N)
         bufs = [(ctx.vec(synth_stream(815 + i, n)), ctx.empty(n)) for i in range(4)]
         def step(i):
             a, b = bufs[i % 4]; f.fwd(a, b, Scale.SN); f.ifwd(a, Scale.SN)      # benches.rs:305-306,352-353
-        samples, name, bytes_ = 2 * n, "C2: FFT-2048 fwd (copy) + ifwd (in place) on a 1 Mi-sample stream", 32 * n
+        job_samples = 2 * n * args.gpus
+        name, bytes_ = "C2: FFT-2048 fwd (copy) + ifwd (in place) on a 1 Mi-sample stream per GPU", 32 * n
+        shard = "one stream per rank"
     elif args.workload == "c5":
-        frames, nb = 64, 9
+        total_frames, nb = 512, 9
+        lo, frames = frame_shard(total_frames, ranks.rank, args.gpus)
         n = 65536 * frames
-        f = ap.HipFft(ctx, 65536, max_batch=frames)
-        bufs = [(ctx.vec(synth_stream(815 + i, n)), ctx.empty((65536 + 65535 * nb) * frames)) for i in range(3)]
+        f = ap.HipFft(ctx, 65536, max_batch=max(frames, 1))
+        nbuf = 2 if frames > 128 else 3
+        bufs = [(ctx.vec(synth_stream(815 + lo + 7919 * i, n)), ctx.empty((65536 + 65535 * nb) * frames)) for i in range(nbuf)]
         def step(i):
-            a, o = bufs[i % 3]; f.ifwd(a, Scale.SN); sampling.interpolate(ctx, a, o, nb, frame_len=65536)
-        samples, name, bytes_ = n, "C5: 64 x 65536-point FFT (Scale::SN) + 10x linear interpolation", 104 * n
+            a, o = bufs[i % nbuf]; f.ifwd(a, Scale.SN); sampling.interpolate(ctx, a, o, nb, frame_len=65536)
+        job_samples = 65536 * total_frames
+        name, bytes_ = "C5: 512 x 65536-point FFT (Scale::SN) + 10x linear interpolation, frame-sharded", 104 * n
+        shard = f"frame_shard: rank 0 owns frames [{lo}, {lo + frames}) of {total_frames}"
     else:
-        frames = 4096
+        n_channels, frames = 8, 4096
+        mine = channel_of(ranks.rank, args.gpus, n_channels)
         n = N * frames
-        rng = np.random.default_rng(815 + ranks.rank)       # one independent channel per rank
         q = modulation.qpsk(ctx)
         f = ap.HipFft(ctx, N, max_batch=frames)
         ref = np.zeros(N, np.complex64); ref[:4] = np.conj(np.array([-1 + 1j, 0, 1 - 1j, 1 - 1j], np.complex64))
         sig = ctx.vec(ref)
-        bits = [modulation.DeviceBits(ctx, 2 * n, rng.integers(0, 2, 2 * n, dtype=np.uint8)) for _ in range(2)]
-        awgn = noise.new(ctx, 0.01, 815 + ranks.rank)
-        txs = [ctx.empty(n) for _ in range(2)]
-        rxb = [modulation.DeviceBits(ctx, 2 * n) for _ in range(2)]
+        chans = []
+        for c in mine:                                          # channel c: its own bits and noise seed (815 + c)
+            rng = np.random.default_rng(815 + c)
+            chans.append((modulation.DeviceBits(ctx, 2 * n, rng.integers(0, 2, 2 * n, dtype=np.uint8)),
+                          noise.new(ctx, 0.01, 815 + c), ctx.empty(n), modulation.DeviceBits(ctx, 2 * n)))
         def step(i):
-            tx = q.modulate(bits[i % 2], out=txs[i % 2]); awgn.apply(tx); f.mul_chain(tx, sig)
-            q.demod_naive(tx, out=rxb[i % 2])
-        samples, name, bytes_ = n, "C4 (one channel per GPU): QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod, 4096 frames", 52 * n
+            for bits, awgn, txb, rxb in chans:
+                tx = q.modulate(bits, out=txb); awgn.apply(tx); f.mul_chain(tx, sig); q.demod_naive(tx, out=rxb)
+        job_samples = n * n_channels
+        name = "C4: 8 channels x (QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod), 4096 frames each"
+        bytes_ = 52 * n * len(mine)
+        shard = f"channel_of: rank 0 runs channels {mine}"
     ranks.barrier(ctx)
+    seen = ranks.ranks_seen()
     nsettle = settle(step, ctx, args.settle_ms)
     for i in range(args.warmup): step(i)
     ranks.barrier(ctx); t0 = time.perf_counter()
     for i in range(args.steps): step(args.warmup + i)
     ctx.sync(); el = ranks.max_over_ranks(time.perf_counter() - t0)
     if ranks.rank == 0:
-        print(json.dumps({"metric": "GSamples/s cf32", "value": round(samples * args.steps * args.gpus / el / 1e9, 3),
-                          "unit": "GSamples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        assert seen == args.gpus, f"collective spans {seen} ranks, --gpus says {args.gpus}"
+        print(json.dumps({"metric": "GSamples/s cf32", "value": round(job_samples * args.steps / el / 1e9, 3),
+                          "unit": "GSamples/s", "n_gpus": seen, "steps": args.steps, "warmup": args.warmup,
                           "settle_launches": nsettle, "ms_per_step": round(el / args.steps * 1e3, 5),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "config": {"workload": name},
-                          "algorithmic_GBps_per_gpu": round(bytes_ * args.steps / el / 1e9, 1)}), flush=True)
+                          "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": name, "partition": shard},
+                          "algorithmic_GBps_rank0": round(bytes_ * args.steps / el / 1e9, 1)}), flush=True)
     ranks.close()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD process
+    (torch.distributed.run) before this process touches torch or the GPU, and leave with its return code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -214,11 +298,16 @@ def main():
                           "load-onset power transient (tools/transient.py: ~25 ms after any idle gap >= 5 ms)")
     ap_.add_argument("--streams", type=int, default=6, help="rotating working set, x 256 MiB (in+out) each")
     ap_.add_argument("--no-cpu-baseline", action="store_true")
-    ap_.add_argument("--no-two-queues", action="store_true",
-                     help="skip the extra leg that issues the same launches alternately on two HIP queues (informational)")
+    ap_.add_argument("--no-overlap", action="store_true",
+                     help="run the timed region on ONE HIP queue (aeth_ctx_set_overlap off): every launch then waits for "
+                          "the previous one to drain; this is also the mode to profile per-kernel durations in")
+    ap_.add_argument("--no-single-queue-leg", action="store_true",
+                     help="skip the extra leg that repeats the timed steps on one queue (per-launch kernel time)")
     ap_.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],
                      help="c3 (default) = the headline config; the others are BASELINE configs 2, 4, 5 for the record")
     args = ap_.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     if args.workload != "c3":
         return side_workload(args)
 
@@ -228,6 +317,11 @@ def main():
     import aether_primitives_amd as ap
     ctx = ap.Context(local_rank)
     fir = ap.Fir(ctx, lowpass_taps(), FFT_LEN)
+    # Two HIP queues inside the context (aeth_ctx_set_overlap): consecutive steps touch different streams, so the
+    # library lets launch k+1 start while launch k drains; anything else on the context (events, copies, syncs)
+    # is ordered behind both queues.  --no-overlap = one queue, one launch at a time.
+    overlap = not args.no_overlap
+    ctx.set_overlap(overlap)
 
     nstreams = max(1, args.streams)
     ins, outs = [], []
@@ -241,26 +335,49 @@ def main():
     def barrier():
         ranks.barrier(ctx)
 
-    ev0, ev1 = ctx.event(), ctx.event()
+    def timed(steps, first):
+        """barrier + sync | `steps` launches | sync: wall seconds (this rank) and HIP-event ms over the same region"""
+        e0, e1 = ctx.event(), ctx.event()
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(steps):
+            step(first + i)
+        e1.record()
+        ctx.sync()
+        ranks.torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return wall, e0.elapsed_ms(e1)
+
     barrier()                  # RCCL sets its communicator up lazily: have that idle gap here, not next to the timed region
+    seen = ranks.ranks_seen()
     # Load-onset transient: after >= 5 ms of idle the GPU runs ~2 ms at full speed, then 10-25 % slower for
     # ~25 ms while its power management settles (profiles/r01_fmi_duration_vs_time.json).  A stream processor
     # lives in the settled state, so reach it before the warm-up; nothing below is skipped or shortened.
     nsettle = settle(step, ctx, args.settle_ms)
     for i in range(args.warmup):
         step(i)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev1.record()
-    ctx.sync()
-    ranks.torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kern_ms = ev0.elapsed_ms(ev1) / max(args.steps, 1)       # per launch, on the kernel's own stream
+    elapsed, ev_ms = timed(args.steps, args.warmup)
+    step_ms = ev_ms / max(args.steps, 1)                      # per step, HIP events on the context's stream
     elapsed = ranks.max_over_ranks(elapsed)
+
+    # Extra leg (rank 0's GPU, untimed for `value`): the same steps on ONE queue.  Per-launch kernel time as
+    # rocprofv3 --kernel-trace sees it (profiles/): with two queues the dispatches overlap and their individual
+    # durations no longer add up to the wall time.
+    single = None
+    if overlap and not args.no_single_queue_leg:
+        ctx.set_overlap(False)
+        for i in range(max(args.warmup, 5)):
+            step(i)
+        w1, e1 = timed(args.steps, args.warmup)
+        ctx.set_overlap(True)
+        k_ms = e1 / max(args.steps, 1)
+        single = {"queues": 1, "kernel_ms": round(k_ms, 5),
+                  "value": round(float(STREAM) * args.steps / w1 / 1e9, 3), "unit": "GSamples/s",
+                  "achieved_GBps": round(BYTES_PER_SAMPLE * STREAM / (k_ms * 1e-3) / 1e9, 1),
+                  "frac": round(BYTES_PER_SAMPLE * STREAM / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "note": "one launch at a time: fill + drain of every launch exposed; this is the duration a "
+                          "kernel trace reports per dispatch"}
     barrier()
     # a plain device copy of the same bytes, same buffers, right behind the timed region (SURVEY 8d: the
     # fraction is reported against the spec peak AND against what a copy reaches on this device)
@@ -272,38 +389,16 @@ def main():
         outs[i % nstreams].vec_clone(ins[i % nstreams])
     c1.record(); ctx.sync()
     copy_gbs = BYTES_PER_SAMPLE * STREAM / (c0.elapsed_ms(c1) / 200 * 1e-3) / 1e9
-    # Informational extra leg (rank 0, one GPU): the same launches issued alternately on TWO queues.  The drain of
-    # one launch then overlaps the fill of the next, which `value` above -- one queue, one launch at a time, the
-    # setting the per-kernel roofline needs -- does not show.
-    two_q = None
-    if args.gpus == 1 and not args.no_two_queues:
-        ctx2 = ap.Context(local_rank)
-        fir2 = ap.Fir(ctx2, lowpass_taps(), FFT_LEN)
-        views = [(ap.context.DeviceVec(ctx2, STREAM, ptr=ins[i].ptr), ap.context.DeviceVec(ctx2, STREAM, ptr=outs[i].ptr))
-                 for i in range(nstreams)]
-        def step2(i):
-            if i & 1: fir2.filter(views[i % nstreams][0], out=views[i % nstreams][1])
-            else: step(i)
-        for i in range(400): step2(i)
-        ctx.sync(); ctx2.sync()
-        tq = time.perf_counter()
-        for i in range(args.steps): step2(i)
-        ctx.sync(); ctx2.sync()
-        tq = time.perf_counter() - tq
-        two_q = {"queues": 2, "value": round(float(STREAM) * args.steps / tq / 1e9, 3), "unit": "GSamples/s",
-                 "pct_of_hbm_roofline": round(100.0 * STREAM * args.steps / tq * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 2),
-                 "note": "same kernel and buffers, consecutive launches alternate over two HIP queues (drain/fill overlap); "
-                         "not the reported value"}
-        del fir2, views
-        ctx2.close()
 
     if rank == 0:
+        assert seen == args.gpus, f"collective spans {seen} ranks, --gpus says {args.gpus}"
         total_samples = float(STREAM) * args.steps * args.gpus
         value = total_samples / elapsed / 1e9
-        achieved = BYTES_PER_SAMPLE * STREAM / (kern_ms * 1e-3) / 1e9
+        achieved = BYTES_PER_SAMPLE * STREAM / (step_ms * 1e-3) / 1e9
+        traffic = measured_traffic() or (None, None)
         line = {
             "metric": "GSamples/s cf32 (FFT-2048 + 64-tap FIR chain)",
-            "value": round(value, 3), "unit": "GSamples/s", "n_gpus": args.gpus, "steps": args.steps,
+            "value": round(value, 3), "unit": "GSamples/s", "n_gpus": seen, "steps": args.steps,
             "warmup": args.warmup, "settle_launches": nsettle, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -311,18 +406,22 @@ def main():
                                    "(one fused kernel launch), device-resident, rotating over "
                                    f"{nstreams} stream pairs = {nstreams * 256} MiB",
                        "fft_len": FFT_LEN, "ntaps": NTAPS, "hop": fir.hop, "samples_per_step": STREAM,
+                       "queues_per_gpu": 2 if overlap else 1,
+                       "launch_overlap": ("consecutive steps (independent streams) alternate between the context's two "
+                                          "HIP queues, at most two launches in flight (aeth_ctx_set_overlap)")
+                                         if overlap else "none: one queue, one launch at a time",
                        "parallelism": f"{args.gpus} independent stream(s), one per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "level": "step (HIP events over the timed region / steps)" + (
+                             "; two launches overlap, see single_queue for the per-dispatch duration" if overlap else ""),
                          "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
-                         "traffic": (measured_traffic() or (None, None))[1],
-                         "traffic_source": (measured_traffic() or (None, None))[0],
-                         "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>>", "kernel_ms": round(kern_ms, 5),
+                         "traffic": traffic[1], "traffic_source": traffic[0],
+                         "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>>", "step_ms": round(step_ms, 5),
                          "bytes_per_launch": BYTES_PER_SAMPLE * STREAM},
-            "pct_of_hbm_roofline": round(100.0 * value / args.gpus * BYTES_PER_SAMPLE / HBM_PEAK_GBS, 2),
         }
-        if two_q is not None:
-            line["two_queues"] = two_q
+        if single is not None:
+            line["single_queue"] = single
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -81,6 +81,13 @@ AETH_API int aeth_ctx_create(int device, aeth_ctx **out);
 AETH_API int aeth_ctx_create_on_stream(int device, void *hip_stream, aeth_ctx **out);
 AETH_API int aeth_ctx_destroy(aeth_ctx *ctx);
 AETH_API int aeth_ctx_sync(aeth_ctx *ctx);
+/* Overlap lane (no reference counterpart: the reference is synchronous; this is the device analogue of keeping
+ * two stages of src/pipeline.rs:52-137 busy).  When enabled, consecutive aeth_fir_exec calls whose buffers do not
+ * touch each other alternate between two HIP queues of the context, so that the end of one launch overlaps the
+ * start of the next; every other call (and aeth_ctx_sync / aeth_event_record) is ordered behind both queues, so
+ * results are those of one in-order stream.  Off by default; refused for contexts on a borrowed stream. */
+AETH_API int aeth_ctx_set_overlap(aeth_ctx *ctx, int enable);
+AETH_API int aeth_ctx_overlap(const aeth_ctx *ctx);   /* 1 if enabled */
 AETH_API void *aeth_ctx_stream(aeth_ctx *ctx);       /* hipStream_t */
 AETH_API int aeth_ctx_device(const aeth_ctx *ctx);
 

@@ -60,6 +60,8 @@ public:
     Context &operator=(const Context &) = delete;
     aeth_ctx *get() const { return h_; }
     void sync() const { check(aeth_ctx_sync(h_)); }
+    // consecutive independent Fir::filter launches alternate between two HIP queues (include/aether_hip.h)
+    void set_overlap(bool enable = true) const { check(aeth_ctx_set_overlap(h_, enable ? 1 : 0)); }
 
 private:
     aeth_ctx *h_ = nullptr;

@@ -30,6 +30,32 @@ def build(force=False):
     return _SO
 
 
+_native = None
+
+
+def native_fir_lib():
+    """Timing build of the same restatement for bench.py's cpu_baseline leg (SURVEY 8d / BASELINE.md 2):
+    `gcc -O3 -march=native -ffp-contract=off`, compiled ON the machine that runs it (oracle/_native/, ignored by
+    git and by gpurun).  Returns (CDLL, flags) or (None, reason) -- the caller then times the portable build."""
+    global _native
+    if _native is not None:
+        return _native
+    out_dir = os.path.join(_HERE, "_native")
+    so = os.path.join(out_dir, "libaeth_oracle_native.so")
+    flags = ["-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=gnu11"]
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["gcc", *flags, "-shared", "-o", so, os.path.join(_HERE, "aeth_oracle.c"), "-lm", "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        L.orc_fir_ols_f32_mt.restype = C.c_int
+        L.orc_fir_ols_f32_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        _native = (L, " ".join(flags))
+    except Exception as e:      # no compiler on the box, read-only tree ...
+        _native = (None, f"native build failed: {e}")
+    return _native
+
+
 _lib = None
 
 

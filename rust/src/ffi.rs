@@ -40,6 +40,8 @@ extern "C" {
     pub fn aeth_event_elapsed_ms(start: *mut aeth_event, stop: *mut aeth_event, ms: *mut c_float) -> c_int;
     pub fn aeth_ctx_destroy(ctx: *mut aeth_ctx) -> c_int;
     pub fn aeth_ctx_sync(ctx: *mut aeth_ctx) -> c_int;
+    pub fn aeth_ctx_set_overlap(ctx: *mut aeth_ctx, enable: c_int) -> c_int;
+    pub fn aeth_ctx_overlap(ctx: *const aeth_ctx) -> c_int;
     pub fn aeth_dev_alloc(ctx: *mut aeth_ctx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
     pub fn aeth_dev_free(ctx: *mut aeth_ctx, dptr: *mut c_void) -> c_int;
     pub fn aeth_upload(ctx: *mut aeth_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;

@@ -40,6 +40,8 @@ impl Context {
         Context { h }
     }
     pub fn sync(&self) { check(unsafe { aeth_ctx_sync(self.h) }) }
+    /// Consecutive independent `Fir::filter` launches alternate between two HIP queues.
+    pub fn set_overlap(&self, enable: bool) { check(unsafe { aeth_ctx_set_overlap(self.h, enable as c_int) }) }
 }
 impl Drop for Context { fn drop(&mut self) { unsafe { aeth_ctx_destroy(self.h); } } }
 
