@@ -57,8 +57,11 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
             return AETH_OK;
         }
     }
-    if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false>), dim3(grid), dim3(C::WG), 0, stream, b);
-    else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false>), dim3(grid), dim3(C::WG), 0, stream, b);
+    // one-frame workgroups run their LDS exchanges at raised wave priority (V_PRIO: -0.3 ... -0.5 us per 16 Mi-sample
+    // launch in tools/fir_lab, A/B in one process); the other variants of aeth_fir_kernel.h measured null or negative
+    constexpr int VAR = (C::F == 1) ? V_PRIO : 0;
+    if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR>), dim3(grid), dim3(C::WG), 0, stream, b);
+    else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false, VAR>), dim3(grid), dim3(C::WG), 0, stream, b);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

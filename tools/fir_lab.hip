@@ -108,6 +108,9 @@ int main(int argc, char **argv)
         {"nobar", 64, 0, 0}, {"nobar/2q", 64, 2, 0}, {"nobar+nomem", 112, 0, 0}, {"nobar+nomem/g512", 112, 0, 512}, {"nobar+nomem/g256", 112, 0, 256},
         {"nolds", 128, 0, 0}, {"nolds+nomem", 176, 0, 0}, {"nolds+nomem/g512", 176, 0, 512}, {"nolds+nomem/g256", 176, 0, 256},
         {"x2", 1000, 0, 512}, {"x2/nomem", 1048, 0, 512}, {"x2/nolds+nomem", 1176, 0, 512},
+        {"base/g1280", 0, 0, 1280}, {"base/g1536", 0, 0, 1536}, {"base/g2048", 0, 0, 2048}, {"base/g3072", 0, 0, 3072}, {"base/g4229", 0, 0, 4229}, {"base/g8457", 0, 0, 8457},
+        {"base/g2048/2q", 0, 2, 2048}, {"base/g4229/2q", 0, 2, 4229},
+        {"nolds/2q", 128, 2, 0}, {"prio/2q", 4, 2, 0}, {"peel/2q", 1, 2, 0},
         {"nomem", 48, 0, 0}, {"nomem/g768", 48, 0, 768}, {"nomem/g512", 48, 0, 512}, {"nomem/g256", 48, 0, 256},
     };
     std::vector<Variant> vs;

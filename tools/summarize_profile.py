@@ -7,7 +7,7 @@ counts 64 B per 128-B request of a wide coalesced stream, i.e. it reads HALF the
 fetched bytes -> doubled here; WRITE_SIZE is exact for streaming stores."""
 import csv, glob, json, os, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 KERNEL = "fmi_kernel"
@@ -18,8 +18,10 @@ def one(pattern):
     return f[-1] if f else None
 
 
-out = {"tag": tag, "command": "python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-two-queues"}
-st = one("trace/*/*_kernel_stats.csv")
+NTIMED = 1000
+out = {"tag": tag, "command_one_queue": "python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-single-queue-leg --no-overlap",
+       "command_two_queues": "python3 bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-single-queue-leg"}
+st = one("trace1q/*/*_kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
@@ -35,9 +37,9 @@ for key, pat in (("FETCH_SIZE", "fetch/*/*_counter_collection.csv"), ("WRITE_SIZ
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
             if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == key]
     if vals:
-        vals = vals[-2000:]                    # the timed launches (settle + warm-up come first)
+        vals = vals[-NTIMED:]                    # the timed launches (settle + warm-up come first)
         out[key + "_KiB_per_launch_raw"] = sum(vals) / len(vals)
-for name in ("trace", "fetch", "write"):
+for name in ("trace1q", "trace2q", "fetch", "write"):
     p = os.path.join(src, f"{name}_bench.json")
     if os.path.exists(p):
         try:
@@ -52,25 +54,35 @@ if "FETCH_SIZE_KiB_per_launch_raw" in out and "WRITE_SIZE_KiB_per_launch_raw" in
     out["hbm_bytes_per_launch"] = rd + wr
     out["algorithmic_bytes_per_launch"] = 16 * (1 << 24)
     out["traffic_over_algorithmic"] = (rd + wr) / (16 * (1 << 24))
-# per-dispatch duration over the run: shows the load-onset power transient and the settled state
-tr = one("trace/*/*_kernel_trace.csv")
+# per-dispatch durations, one queue: the last NTIMED dispatches are the timed region
+tr = one("trace1q/*/*_kernel_trace.csv")
 if tr:
     rows = [r for r in csv.DictReader(open(tr)) if KERNEL in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     if rows:
-        t0 = int(rows[0]["Start_Timestamp"])
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows][-NTIMED:]
+        out["one_queue_timed_launches_avg_us"] = sum(durs) / len(durs)
+        out["one_queue_timed_launches_min_us"] = min(durs)
+        out["one_queue_timed_launches_max_us"] = max(durs)
+# two queues: dispatches overlap, so the per-dispatch duration is no longer the step time; the step time is the
+# start-to-start (= end-to-end) interval of consecutive dispatches
+tr = one("trace2q/*/*_kernel_trace.csv")
+if tr:
+    rows = [r for r in csv.DictReader(open(tr)) if KERNEL in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[-NTIMED:]
+    if len(rows) > 10:
+        st_ = [int(r["Start_Timestamp"]) for r in rows]; en = sorted(int(r["End_Timestamp"]) for r in rows)
         durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-        timed = durs[-2000:]
-        out["timed_launches_avg_us"] = sum(timed) / len(timed)
-        out["timed_launches_min_us"] = min(timed)
-        out["timed_launches_max_us"] = max(timed)
-        pts = [{"launch": i, "t_ms": round((int(r["Start_Timestamp"]) - t0) / 1e6, 3), "dur_us": round(durs[i], 2)}
-               for i, r in enumerate(rows) if i < 40 or i % 25 == 0]
-        json.dump({"note": "per-dispatch duration of fmi_kernel over one bench run (rocprofv3 --kernel-trace, "
-                           "python3 bench.py --steps 2000 --warmup 200): ~2 ms at full speed after the idle gap, "
-                           "then 10-25 % slower for ~25 ms while the power management settles, then steady; "
-                           "bench.py's untimed settle phase + warm-up cover the transient, the last 2000 "
-                           "dispatches are the timed region", "dispatches": pts},
-                  open(f"profiles/{tag}_fmi_duration_vs_time.json", "w"))
+        out["two_queues"] = {
+            "dispatches": len(rows),
+            "per_dispatch_duration_avg_us": sum(durs) / len(durs),
+            "start_to_start_avg_us": (st_[-1] - st_[0]) / 1e3 / (len(rows) - 1),
+            "end_to_end_avg_us": (en[-1] - en[0]) / 1e3 / (len(rows) - 1),
+            "queues_seen": sorted({r.get("Queue_Id", "?") for r in rows}),
+            "avg_dispatches_in_flight": sum(durs) * 1e3 / max(en[-1] - st_[0], 1),
+            "note": "two dispatches in flight: each one's own duration spans the tail of its predecessor and the "
+                    "head of its successor, so durations sum to more than the wall time; throughput = one launch "
+                    "per end_to_end interval"}
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("bench_line")}, indent=1))
