@@ -51,6 +51,7 @@ PROTOTYPES = {
     "aeth_vec_clone": (i32, [vp, vp, sz, vp, sz]),
     "aeth_vec_zero": (i32, [vp, vp, sz]),
     "aeth_vec_mirror_frames": (i32, [vp, vp, sz, sz]),
+    "aeth_vec_mul_frames": (i32, [vp, vp, sz, sz, vp, sz]),
     "aeth_host_vec_scale": (i32, [vp, vp, sz, f32]),
     "aeth_host_vec_mul": (i32, [vp, vp, sz, vp, sz]),
     "aeth_host_vec_div": (i32, [vp, vp, sz, vp, sz]),
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "aeth_fft_len": (sz, [vp]),
     "aeth_fft_algorithm": (C.c_char_p, [vp]),
     "aeth_fft_exec": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
+    "aeth_fft_exec_mirrored": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
     "aeth_fft_exec_host": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
     "aeth_fft_exec_tmp_host": (i32, [vp, vp, sz, i32, i32, f32, pvp]),
     "aeth_fft_exec_tmp": (i32, [vp, vp, sz, sz, i32, i32, f32, pvp]),
@@ -77,6 +79,7 @@ PROTOTYPES = {
     "aeth_fir_fft_len": (sz, [vp]),
     "aeth_fir_hop": (sz, [vp]),
     "aeth_fir_exec": (i32, [vp, vp, vp, sz, vp]),
+    "aeth_fir_exec_decim": (i32, [vp, vp, vp, sz, vp, sz]),
     "aeth_fir_exec_host": (i32, [vp, vp, vp, sz, vp]),
     "aeth_fir_stream_host": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_fir_stream_file": (i32, [vp, C.c_char_p, C.c_char_p, sz, vp]),
@@ -91,6 +94,8 @@ PROTOTYPES = {
     "aeth_modulate": (i32, [vp, vp, sz, i32, vp, vp, sz]),
     "aeth_demod_naive": (i32, [vp, vp, sz, i32, vp, vp, sz, i32]),
     "aeth_awgn_apply": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
+    "aeth_awgn_fill": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
+    "aeth_rng_philox4x32_10": (i32, [vp, vp, sz, vp]),
 }
 
 _lib = None

@@ -182,6 +182,11 @@ class DeviceVec:
     def vec_mirror(self):                                         # vecops.rs:54
         check(self.ctx._lib.aeth_vec_mirror(self.ctx.h, self._p(), self.n)); return self
 
+    def vec_mul_frames(self, sig, frame_len=None):
+        """every frame of `frame_len` samples *= sig (one launch; benches.rs:410-416's vec_mul per chunk)"""
+        o = self._other(sig); L = frame_len or o.n
+        check(self.ctx._lib.aeth_vec_mul_frames(self.ctx.h, self._p(), L, self.n // L if L else 0, o._p(), o.n)); return self
+
     def vec_mirror_frames(self, frame_len):
         check(self.ctx._lib.aeth_vec_mirror_frames(self.ctx.h, self._p(), frame_len, self.n // frame_len)); return self
 

@@ -53,8 +53,12 @@ template <class C> struct SingleImage : C {
 // NT: frames are streamed with the non-temporal hint (batches beyond the cache; aeth_internal.h)
 template <class C0, int S, bool NT>
 __global__ __launch_bounds__(C0::WG) void fft_pow2_kernel(const cf *in, cf *out,
-                                                          const cf *__restrict__ twL, size_t batch, float scale)
+                                                          const cf *__restrict__ twL, size_t batch, float scale, int mirror)
 {
+    // mirror: the frame is stored with its halves swapped (vec_mirror, vecops.rs:157-161, behind vec_rfft as in
+    // util/plot.rs:59-61): output slot m goes where slot m ^ P/2 would, i.e. element e to e ^ N/2 -- two base
+    // offsets instead of one, no extra pass over memory
+    const int msh = mirror ? (C0::P / 2) * C0::T : 0;
     constexpr bool STAGED = pow2_staged_io<C0>();
     // staged configurations: ONE exchange image, and the I/O staging area shares its LDS (the image is idle
     // while frames are copied in and out) -- LDS per workgroup is what bounds the waves per CU here
@@ -114,7 +118,8 @@ __global__ __launch_bounds__(C0::WG) void fft_pow2_kernel(const cf *in, cf *out,
             __syncthreads();
             if (fl < C::F) {
 #pragma unroll
-                for (int m = 0; m < C::P; m++) lds_io[fl * (C::N + 1) + tid + m * C::T] = cscale_k(w[m], ss);
+                for (int m = 0; m < C::P; m++)
+                    lds_io[fl * (C::N + 1) + tid + m * C::T + (m < C::P / 2 ? msh : -msh)] = cscale_k(w[m], ss);
             }
             __syncthreads();
 #pragma unroll
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(C0::WG) void fft_pow2_kernel(const cf *in, cf *out,
             }
         } else if (active) {
 #pragma unroll
-            for (int m = 0; m < C::P; m++) aeth::nt_store<NT>(dst + m * C::T, cscale_k(w[m], ss));
+            for (int m = 0; m < C::P; m++) aeth::nt_store<NT>(dst + m * C::T + (m < C::P / 2 ? msh : -msh), cscale_k(w[m], ss));
         }
     }
 }
@@ -137,8 +142,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 template <class C, int S, bool NT>
 __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf *out, const cf *__restrict__ twL,
-                                                                 size_t batch, float scale)
+                                                                 size_t batch, float scale, int mirror)
 {
+    const int msh = mirror ? (C::P / 2) * C::T * 8 : 0;      // see fft_pow2_kernel
     static_assert(C::F == 1, "one frame per workgroup");
     __shared__ cf lds[C::LDS_TOTAL];
     const int tid = threadIdx.x;
@@ -169,12 +175,12 @@ __global__ __launch_bounds__(C::WG) void fft_pow2_stream_kernel(const cf *in, cf
         auto ws = __builtin_amdgcn_make_buffer_rsrc(out + g * C::N, 0, C::N * 8, 0x00020000);
 #pragma unroll
         for (int m = 0; m < C::P; m++)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8, 0, NT ? 18 : 0);   // aux: bit 1 = non-temporal, bit 4 = sc1 (tools/nt_modes.hip)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cscale_k(w[m], ss)), ws, (tid + m * C::T) * 8 + (m < C::P / 2 ? msh : -msh), 0, NT ? 18 : 0);   // aux: bit 1 = non-temporal, bit 4 = sc1 (tools/nt_modes.hip)
     }
 }
 
 template <class C>
-int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale, int mirror)
 {
     const aeth_ctx *ctx = plan->ctx;
     const bool nt = aeth::streams_past_cache(2 * batch * (size_t)C::N * sizeof(float2));
@@ -188,7 +194,7 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
         int grid2 = (int)(batch < cap2 ? batch : cap2);
         if (grid2 < 1) grid2 = 1;
         if (!aeth::tuning_int("AETH_FFT_NOSTREAM", 0)) {
-#define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+#define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale, mirror)
             if (sign > 0) { if (nt) AETH_FFT_STREAM(+1, true); else AETH_FFT_STREAM(+1, false); }
             else          { if (nt) AETH_FFT_STREAM(-1, true); else AETH_FFT_STREAM(-1, false); }
 #undef AETH_FFT_STREAM
@@ -196,7 +202,7 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
             return AETH_OK;
         }
     }
-#define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale)
+#define AETH_FFT_PLAIN(SS, NN) hipLaunchKernelGGL((fft_pow2_kernel<C, SS, NN>), dim3(grid), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale, mirror)
     if (sign > 0) { if (nt) AETH_FFT_PLAIN(+1, true); else AETH_FFT_PLAIN(+1, false); }
     else          { if (nt) AETH_FFT_PLAIN(-1, true); else AETH_FFT_PLAIN(-1, false); }
 #undef AETH_FFT_PLAIN
@@ -204,9 +210,9 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
     return AETH_OK;
 }
 
-int dispatch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
+int dispatch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale, int mirror = 0)
 {
-#define AETH_BODY(NN) return launch_pow2<typename CfgFor<NN>::type>(plan, in, out, batch, sign, scale)
+#define AETH_BODY(NN) return launch_pow2<typename CfgFor<NN>::type>(plan, in, out, batch, sign, scale, mirror)
     AETH_POW2_SWITCH_XL(plan->len, AETH_BODY, return aeth::set_error(AETH_E_UNSUPPORTED, "stockham_pow2: length %zu", plan->len))
 #undef AETH_BODY
 }
@@ -750,6 +756,25 @@ int aeth_fft_exec(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out,
     AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out), AETH_E_ALIGN, "pointer not 8-byte aligned");
     const float s = aeth_scale_factor(kind, p->len, x);                     /* fft.rs:22-37, n = frame length */
     return aeth::fft_run(p, (const float2 *)in, (float2 *)out, batch, sign, s);
+}
+
+/* c.vec_rfft(&mut fft, s).vec_mirror() per frame (src/util/plot.rs:59-61) in one call */
+int aeth_fft_exec_mirrored(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out, size_t batch, int sign,
+                           int kind, float x)
+{
+    int rc = check_exec(p, sign, kind); if (rc) return rc;
+    AETH_REQUIRE(n_in == batch * p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);     /* fft.rs:163-167 */
+    if (batch == 0) return AETH_OK;
+    AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out), AETH_E_ALIGN, "pointer not 8-byte aligned");
+    const float s = aeth_scale_factor(kind, p->len, x);
+    if (p->algo == aeth::FFT_ALGO_POW2 && p->len >= 2) {
+        // register-resident transforms: the swap of the halves is folded into the store addresses
+        aeth::DeviceGuard dev_guard(p->ctx->device);
+        return dispatch_pow2(p, (const float2 *)in, (float2 *)out, batch, sign, s, 1);
+    }
+    rc = aeth::fft_run(p, (const float2 *)in, (float2 *)out, batch, sign, s); if (rc) return rc;
+    return aeth_vec_mirror_frames(p->ctx, out, p->len, batch);              /* vecops.rs:157-161 per frame */
 }
 
 int aeth_fft_exec_tmp(aeth_fft *p, const aeth_cf32 *in, size_t n_in, size_t batch, int sign, int kind, float x,

@@ -60,6 +60,14 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     // one-frame workgroups run their LDS exchanges at raised wave priority (V_PRIO: -0.3 ... -0.5 us per 16 Mi-sample
     // launch in tools/fir_lab, A/B in one process); the other variants of aeth_fir_kernel.h measured null or negative
     constexpr int VAR = (C::F == 1) ? V_PRIO : 0;
+    if constexpr (C::F == 1 && !SCALED) {
+        if (b.dec.d > 1) {                                  // decimating store (aeth_fir_exec_decim)
+            if (nt) hipLaunchKernelGGL((fmi_kernel<C, false, 1, true, false, VAR | V_DECIM>), dim3(grid), dim3(C::WG), 0, stream, b);
+            else hipLaunchKernelGGL((fmi_kernel<C, false, 1, false, false, VAR | V_DECIM>), dim3(grid), dim3(C::WG), 0, stream, b);
+            AETH_HIP(hipGetLastError());
+            return AETH_OK;
+        }
+    }
     if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR>), dim3(grid), dim3(C::WG), 0, stream, b);
     else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false, VAR>), dim3(grid), dim3(C::WG), 0, stream, b);
     AETH_HIP(hipGetLastError());
@@ -119,8 +127,7 @@ int aeth_fft_mul_ifft(aeth_fft *plan, aeth_cf32 *frames, size_t n_total, size_t 
         // generic lengths (and the 8192-point frame, too wide for the fused kernel's registers): the three trait calls, unfused
         int rc = aeth_fft_exec(plan, frames, n_total, frames, batch, AETH_SIGN_REF_FWD, kind_fwd, x_fwd);
         if (rc) return rc;
-        for (size_t f = 0; f < batch && rc == AETH_OK; f++)
-            rc = aeth_vec_mul(plan->ctx, frames + f * plan->len, plan->len, sig, n_sig);
+        rc = aeth_vec_mul_frames(plan->ctx, frames, plan->len, batch, sig, n_sig);    // one launch, sig shared by every frame
         if (rc) return rc;
         return aeth_fft_exec(plan, frames, n_total, frames, batch, AETH_SIGN_REF_BWD, kind_bwd, x_bwd);
     }
@@ -206,6 +213,33 @@ int aeth_fir_exec(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_
     hipStream_t lane = hist ? aeth::ctx_stream(f->ctx)
                             : aeth::ctx_fir_lane(f->ctx, (uintptr_t)in, (uintptr_t)(in + n), (uintptr_t)out, (uintptr_t)(out + n));
     return dispatch_fmi(f->ctx, f->fft_len, a, lane);
+}
+
+/* fir, then sampling::downsample(&y, &mut dst) (src/sampling.rs:28-42) in one pass: out[i] = y[i * dec],
+ * dec = n / n_out; the filter's kernel simply does not store the samples downsample would skip */
+int aeth_fir_exec_decim(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t n_out)
+{
+    AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
+    if (n == 0 && n_out == 0) return AETH_OK;
+    AETH_REQUIRE(n_out > 0 && n % n_out == 0, AETH_E_ARG, AETH_MSG_DECIM);          /* sampling.rs:32-36 */
+    const size_t dec = n / n_out;
+    if (dec == 1) return aeth_fir_exec(f, hist, in, n, out);
+    AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(in != out, AETH_E_ARG, "FIR cannot run in place (blocks overlap)");
+    AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out) && aeth::aligned8(hist), AETH_E_ALIGN,
+                 "pointer not 8-byte aligned");
+    AETH_REQUIRE(f->fft_len >= 1024 && f->fft_len <= 4096, AETH_E_UNSUPPORTED,
+                 "decimating store: fft_len %zu (one-block-per-workgroup lengths 1024 .. 4096 only)", f->fft_len);
+    AETH_REQUIRE(n < ((size_t)1 << 31), AETH_E_UNSUPPORTED, "decimating store: %zu samples (32-bit index arithmetic)", n);
+    FmiArgs a;
+    a.dbg = 0;
+    a.in = (const cf *)in; a.out = (cf *)out; a.hist = (const cf *)hist; a.Hf = (const cf *)f->Hf;
+    a.twN = (const cf *)f->fft->tw_dev; a.twL = (const cf *)f->fft->tw_lane_dev;
+    a.n = (long long)n; a.hop = (int)f->hop; a.ov = (int)(f->fft_len - f->hop); a.nhist = (int)(f->ntaps - 1);
+    a.nblocks = (long long)((n + f->hop - 1) / f->hop);
+    a.s_fwd = 1.0f; a.s_bwd = 1.0f;
+    a.dec = aeth::make_fastdiv((uint32_t)dec); a.n_out = (long long)n_out;
+    return dispatch_fmi(f->ctx, f->fft_len, a, aeth::ctx_stream(f->ctx));
 }
 
 }  // extern "C"

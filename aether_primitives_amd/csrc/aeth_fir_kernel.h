@@ -30,6 +30,9 @@ struct FmiArgs {
     const cf *chirp = nullptr;
     int frame_n = 0;      // valid samples per window (0: the whole window)
     int conj = 0;
+    // V_DECIM: only every dec-th output sample is stored, out[i] = y[i * dec] (fir -> sampling::downsample in one pass)
+    aeth::FastDiv dec = {1, 0, 0, 0};
+    long long n_out = 0;  // samples in `out` = n / dec
 };
 
 // Kernel variants (template parameter VAR, a bit set).  0 is the round-1 kernel.
@@ -40,6 +43,7 @@ enum : int {
                     // Infinity Cache so that the register prefetch one round later is served on-die
     V_PRIO  = 4,    // s_setprio 1 around every LDS exchange (its latency chain is what a block's time is made of)
     V_TOUCH3 = 8,   // with V_TOUCH: three rounds ahead instead of two
+    V_DECIM = 512,  // product variant: decimating store (aeth_fir_exec_decim)
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
     V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
     V_CENSUS = 256, // diagnosis only: every wave records HW_ID / XCC_ID in the buffer passed as `chirp`
@@ -152,12 +156,32 @@ __device__ __forceinline__ unsigned touch_window(const FmiArgs &a, long long blk
 
 // CHECK = false: the caller knows that the block exists (no branch around the stores, so that hipcc keeps
 // counting the memory operations in flight across them)
-template <class C, bool SCALED, bool NT, bool CHECK = true>
+template <class C, bool SCALED, bool NT, bool CHECK = true, bool DECIM = false>
 __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
 {
     if constexpr (CHECK) { if (blk >= a.nblocks) return; }
     const long long base = blk * a.hop - a.ov;              // output index of window element 0
-    if constexpr (C::F == 1) {
+    if constexpr (C::F == 1 && DECIM) {
+        // sampling::downsample behind the filter (sampling.rs:28-42: dst[i] = src[i * dec]) folded into the store:
+        // output sample o of the stream is kept iff dec divides it, and lands at out[o / dec].  32-bit index
+        // arithmetic (the host side checks n < 2^31); q0 = first kept index of this block, descriptor from there.
+        const unsigned o0 = (unsigned)(blk * a.hop);                              // first output sample of the block
+        const unsigned q0 = aeth::fdiv(o0 + a.dec.d - 1, a.dec);
+        const long long left = a.n_out - (long long)q0;
+        const int bytes = left > 0 ? (int)(left < (long long)C::N ? left : (long long)C::N) * 8 : 0;
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + q0, 0, bytes, 0x00020000);
+        const cf ss = mk(a.s_bwd, a.s_bwd);
+#pragma unroll
+        for (int m = 0; m < C::P; m++) {
+            const int e = tid + m * C::T;
+            const unsigned o = o0 + (unsigned)(e - a.ov);                         // meaningful for e >= ov only
+            const unsigned q = aeth::fdiv(o, a.dec);
+            const bool keep = e >= a.ov && q * a.dec.d == o && (long long)o < a.n;
+            const int off = keep ? (int)(q - q0) * 8 : 0x7ffffff0;
+            cf v = SCALED ? cscale_k(w[m], ss) : w[m];
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 18 : 0);
+        }
+    } else if constexpr (C::F == 1) {
         long long left = a.n - base;
         int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;   // stores past the end (of the stream, of the frame) are dropped by the range check
         auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + base, 0, bytes, 0x00020000);
@@ -264,7 +288,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         }
         if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f);
         transform_block<C, SCALED, BLU, VAR>(w, tw, H, lds, a, tid);
-        store_block<C, SCALED, NT, false>(w, a, g0, tid);          // grid <= ngroups: the block exists
+        store_block<C, SCALED, NT, false, (VAR & V_DECIM) != 0>(w, a, g0, tid);          // grid <= ngroups: the block exists
         g0 += gridDim.x;
     } else {
         // software pipeline: the next block's window is in flight while this one is transformed.
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         if constexpr (VAR & V_NOSTORE) {
 #pragma unroll
             for (int m = 0; m < C::P; m++) asm volatile("" ::"v"(w[m]));
-        } else store_block<C, SCALED, NT>(w, a, blk, tid);
+        } else store_block<C, SCALED, NT, true, (VAR & V_DECIM) != 0>(w, a, blk, tid);
     }
     if constexpr (TOUCH) asm volatile("" ::"v"(tprev));
 }

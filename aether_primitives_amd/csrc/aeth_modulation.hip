@@ -98,6 +98,56 @@ __global__ __launch_bounds__(kBlock) void demod_kernel(const float2 *__restrict_
     }
 }
 
+// ---- any implementor of trait Modulation with a symbol table (3 .. 8 bits per symbol): the trait's DEFAULT methods,
+// modulation.rs:94-149.  index() = sum((bit % 2) << i) (:105-111); demod_naive scans candidates
+// 0 .. BITS_PER_SYMBOL*2 (:135 -- not 2^BITS_PER_SYMBOL: reproduced when compat != 0, all 2^bps otherwise) and emits
+// (idx >> i) & 1 (:143).  The table (<= 256 entries, 2 KiB) travels in the kernel arguments and is staged in LDS.
+struct TableN { float2 s[256]; };
+inline unsigned grid_for(size_t items);
+
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void modulate_generic_kernel(const uint8_t *__restrict__ bits, float2 *__restrict__ out,
+                                                                  size_t nsym, int bps, TableN t)
+{
+    __shared__ float2 tab[256];
+    for (int k = threadIdx.x; k < (1 << bps); k += kBlock) tab[k] = t.s[k];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nsym) return;
+    unsigned idx = 0;
+    for (int k = 0; k < bps; k++) idx += (unsigned)(bits[i * (size_t)bps + k] % 2u) << k;      // :107-110
+    aeth::nt_store<NT>(out + i, tab[idx]);                                                      // :115-121
+}
+
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void demod_generic_kernel(const float2 *__restrict__ sym, uint8_t *__restrict__ bits,
+                                                               size_t nsym, int bps, int ncand, TableN t)
+{
+    __shared__ float2 tab[256];
+    for (int k = threadIdx.x; k < ncand; k += kBlock) tab[k] = t.s[k];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nsym) return;
+    const float2 v = aeth::nt_load<NT>(sym + i);
+    unsigned best = 0;
+    float bd = 0.f;
+    for (int c = 0; c < ncand; c++) {
+        const float dr = v.x - tab[c].x, di = v.y - tab[c].y;                                   // :136
+        const float d = dr * dr + di * di;                                                      // :137
+        if (c == 0 || d < bd) { best = (unsigned)c; bd = d; }                                   // first minimum (:139)
+    }
+    for (int k = 0; k < bps; k++) bits[i * (size_t)bps + k] = (uint8_t)((best >> k) & 1u);      // :143
+}
+
+int fill_table_n(TableN &t, int bps, const aeth_cf32 *host)
+{
+    AETH_REQUIRE(bps >= 3 && bps <= 8, AETH_E_UNSUPPORTED, "bits_per_symbol %d: 1 .. 8 supported", bps);
+    AETH_REQUIRE(host, AETH_E_ARG, "bits_per_symbol %d needs a symbol table (the reference only ships BPSK and QPSK)", bps);
+    for (int i = 0; i < 256; i++) t.s[i] = make_float2(0.f, 0.f);
+    for (int i = 0; i < (1 << bps); i++) t.s[i] = make_float2(host[i].re, host[i].im);
+    return AETH_OK;
+}
+
 int fill_table(Table4 &t, int bps, const aeth_cf32 *host)
 {
     AETH_REQUIRE(bps == 1 || bps == 2, AETH_E_UNSUPPORTED, "bits_per_symbol %d: only BPSK (1) and QPSK (2) tables exist in the reference", bps);
@@ -118,6 +168,20 @@ int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, con
                   size_t n_out)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    if (bps > 2) {
+        TableN tn;
+        int rcn = fill_table_n(tn, bps, table); if (rcn) return rcn;
+        AETH_REQUIRE(nbits % (size_t)bps == 0, AETH_E_LEN, "bit count %zu is not a multiple of BITS_PER_SYMBOL %d", nbits, bps);
+        AETH_REQUIRE(n_out == nbits / (size_t)bps, AETH_E_LEN, "output holds %zu symbols, input gives %zu", n_out, nbits / (size_t)bps);
+        if (n_out == 0) return AETH_OK;
+        AETH_REQUIRE(bits && out, AETH_E_ARG, "null pointer");
+        AETH_REQUIRE(aeth::aligned8(out), AETH_E_ALIGN, "pointer alignment");
+        aeth::DeviceGuard dg(ctx->device);
+        auto k = aeth::streams_past_cache(n_out * sizeof(float2)) ? modulate_generic_kernel<true> : modulate_generic_kernel<false>;
+        hipLaunchKernelGGL(k, dim3(grid_for(n_out)), dim3(kBlock), 0, aeth::ctx_stream(ctx), bits, (float2 *)out, n_out, bps, tn);
+        AETH_HIP(hipGetLastError());
+        return AETH_OK;
+    }
     Table4 t;
     int rc = fill_table(t, bps, table); if (rc) return rc;
     AETH_REQUIRE(nbits % (size_t)bps == 0, AETH_E_LEN, "bit count %zu is not a multiple of BITS_PER_SYMBOL %d", nbits, bps);
@@ -148,6 +212,20 @@ int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym, size_t nsym, int bps, 
                      size_t nbits_out, int compat)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    if (bps > 2) {
+        TableN tn;
+        int rcn = fill_table_n(tn, bps, table); if (rcn) return rcn;
+        AETH_REQUIRE(nbits_out == nsym * (size_t)bps, AETH_E_LEN, "output holds %zu bits, input gives %zu", nbits_out, nsym * (size_t)bps);
+        if (nsym == 0) return AETH_OK;
+        AETH_REQUIRE(sym && bits, AETH_E_ARG, "null pointer");
+        AETH_REQUIRE(aeth::aligned8(sym), AETH_E_ALIGN, "pointer alignment");
+        aeth::DeviceGuard dg(ctx->device);
+        const int ncand = compat ? ((2 * bps < (1 << bps)) ? 2 * bps : (1 << bps)) : (1 << bps);   // modulation.rs:135
+        auto k = aeth::streams_past_cache(nsym * sizeof(float2)) ? demod_generic_kernel<true> : demod_generic_kernel<false>;
+        hipLaunchKernelGGL(k, dim3(grid_for(nsym)), dim3(kBlock), 0, aeth::ctx_stream(ctx), (const float2 *)sym, bits, nsym, bps, ncand, tn);
+        AETH_HIP(hipGetLastError());
+        return AETH_OK;
+    }
     Table4 t;
     int rc = fill_table(t, bps, table); if (rc) return rc;
     AETH_REQUIRE(nbits_out == nsym * (size_t)bps, AETH_E_LEN, "output holds %zu bits, input gives %zu", nbits_out, nsym * (size_t)bps);

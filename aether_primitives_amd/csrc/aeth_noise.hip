@@ -58,9 +58,75 @@ __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__
     }
 }
 
+// Awgn::fill / Awgn::iter (noise.rs:61-84): target[i] = next() = (N(0,1) as f32 * scale, ...), scaled ONCE
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void awgn_fill_kernel(float2 *__restrict__ x, size_t n, float scale,
+                                                           uint64_t seed, uint64_t offset, int wide)
+{
+    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t i0 = 2 * p;
+    if (i0 >= n) return;
+    float n0r, n0i, n1r = 0.f, n1i = 0.f;
+    if ((offset & 1) == 0) {
+        uint32_t w[4];
+        const uint64_t call = (offset + i0) >> 1;
+        aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
+        aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
+    } else {
+        aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
+        if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
+    }
+    if (wide && i0 + 1 < n) {
+        aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), make_float4(n0r * scale, n0i * scale, n1r * scale, n1i * scale));
+    } else {
+        x[i0] = make_float2(n0r * scale, n0i * scale);
+        if (i0 + 1 < n) x[i0 + 1] = make_float2(n1r * scale, n1i * scale);
+    }
+}
+
+// the generator's integer stage on its own: out[i] = Philox4x32-10(counter = in[i][0..3], key = in[i][4..5])
+__global__ __launch_bounds__(kBlock) void philox_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[4];
+    aeth_philox4x32_10(in[6 * i], in[6 * i + 1], in[6 * i + 2], in[6 * i + 3], in[6 * i + 4], in[6 * i + 5], w);
+    out[4 * i] = w[0]; out[4 * i + 1] = w[1]; out[4 * i + 2] = w[2]; out[4 * i + 3] = w[3];
+}
+
 }  // namespace
 
 extern "C" {
+
+int aeth_awgn_fill(aeth_ctx *ctx, aeth_cf32 *target, size_t n, float power, uint64_t seed, uint64_t offset)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    if (n == 0) return AETH_OK;
+    AETH_REQUIRE(target, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(target), AETH_E_ALIGN, "target not 8-byte aligned");
+    AETH_REQUIRE(power >= 0.0f, AETH_E_ARG, "noise power must be >= 0");
+    const float scale = sqrtf(power);                       // noise.rs:35
+    aeth::DeviceGuard dev_guard(ctx->device);
+    const size_t pairs = (n + 1) / 2;
+    auto kern = aeth::streams_past_cache(n * sizeof(float2)) ? awgn_fill_kernel<true> : awgn_fill_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
+                       reinterpret_cast<float2 *>(target), n, scale, seed, offset, aeth::aligned16(target) ? 1 : 0);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+int aeth_rng_philox4x32_10(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, uint32_t *out_dev)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    if (n == 0) return AETH_OK;
+    AETH_REQUIRE(ctr_key_dev && out_dev, AETH_E_ARG, "null pointer");
+    aeth::DeviceGuard dev_guard(ctx->device);
+    hipLaunchKernelGGL(philox_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
+                       ctr_key_dev, out_dev, n);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
 
 int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal, size_t n, float power, uint64_t seed, uint64_t offset)
 {

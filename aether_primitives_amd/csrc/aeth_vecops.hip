@@ -107,6 +107,37 @@ int launch_ew(aeth_ctx *ctx, aeth_cf32 *self, const aeth_cf32 *other, size_t n, 
     return AETH_OK;
 }
 
+// ---- frames[f][j] *= sig[j]: vec_mul with one operand shared by every frame ------------------------------
+// (the middle of `c.vec_rfft(fft, s).vec_mul(&sig).vec_rifft(fft, s)` over chunks_mut(fft_len), benches.rs:410-416
+// and util/plot.rs:59-61).  One launch for any number of frames: grid.x covers a frame, grid.y walks the frames.
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void mul_frames_kernel(float2 *__restrict__ frames, const float2 *__restrict__ sig,
+                                                            size_t frame_len, size_t batch)
+{
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= frame_len) return;
+    const float2 b = sig[j];                                    // re-read by every frame: stays in cache
+    for (size_t f = blockIdx.y; f < batch; f += gridDim.y) {
+        float2 *p = frames + f * frame_len + j;
+        aeth::nt_store<NT>(p, apply2<OP_MUL>(aeth::nt_load<NT>(p), b, 0.f));
+    }
+}
+
+int launch_mul_frames(aeth_ctx *ctx, aeth_cf32 *frames, size_t frame_len, size_t batch, const aeth_cf32 *sig)
+{
+    if (frame_len == 0 || batch == 0) return AETH_OK;
+    aeth::DeviceGuard dev_guard(ctx->device);
+    const bool nt = aeth::streams_past_cache(2 * batch * frame_len * sizeof(float2));
+    const size_t gx = (frame_len + kBlock - 1) / kBlock;
+    // enough workgroups to fill the chip, at most 65535 rows of them
+    size_t gy = batch < 65535 ? batch : 65535;
+    auto k = nt ? mul_frames_kernel<true> : mul_frames_kernel<false>;
+    hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, aeth::ctx_stream(ctx),
+                       reinterpret_cast<float2 *>(frames), reinterpret_cast<const float2 *>(sig), frame_len, batch);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
 // ---- mirror: swap(x, x+mid), mid = len/2, per frame (vecops.rs:157-161) --------
 template <typename V, bool NT>
 __global__ __launch_bounds__(kBlock) void mirror_kernel(V *__restrict__ x, size_t frame_stride_v, size_t mid_v,
@@ -209,6 +240,15 @@ int aeth_vec_mirror_frames(aeth_ctx *ctx, aeth_cf32 *x, size_t frame_len, size_t
 {
     int rc = check_unary(ctx, x, frame_len * batch); if (rc) return rc;
     return launch_mirror(ctx, x, frame_len, batch);
+}
+int aeth_vec_mul_frames(aeth_ctx *ctx, aeth_cf32 *frames, size_t frame_len, size_t batch, const aeth_cf32 *sig, size_t n_sig)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    AETH_REQUIRE(n_sig == frame_len, AETH_E_LEN, AETH_MSG_VEC_LEN);            /* vecops.rs:100-104, per frame */
+    if (frame_len == 0 || batch == 0) return AETH_OK;
+    AETH_REQUIRE(frames && sig, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(frames) && aeth::aligned8(sig), AETH_E_ALIGN, "pointer not 8-byte aligned");
+    return launch_mul_frames(ctx, frames, frame_len, batch, sig);
 }
 int aeth_vec_add(aeth_ctx *ctx, aeth_cf32 *a, size_t n, const aeth_cf32 *b, size_t nb)
 {

@@ -104,6 +104,14 @@ class HipFft:
     def ibwd(self, inp, s):                                       # fft.rs:63, :195-204
         return self.exec(inp, inp, SIGN_REF_BWD, s)
 
+    def rfft_mirror(self, frames, s=Scale.NONE, out=None):
+        """every frame: vec_rfft(self, s) then vec_mirror() (util/plot.rs:59-61), one call; in place unless out="""
+        out = frames if out is None else out
+        n = self.len()
+        check(self._lib.aeth_fft_exec_mirrored(self.h, frames._p(), frames.n, out._p(), frames.n // n if n else 0,
+                                               SIGN_REF_FWD, s.kind, s.x))
+        return out
+
     def _tmp(self, inp, sign, s):
         view = C.c_void_p()
         if _is_dev(inp):

@@ -53,6 +53,15 @@ class Fir:
                                            out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def filter_decim(self, x, dec, out=None, hist=None):
+        """filter, keep every dec-th output: sampling::downsample(&fir(x), &mut out) (sampling.rs:28-42) in one launch"""
+        n_out = x.n // dec if dec else 0
+        if out is None:
+            out = DeviceVec(self.ctx, n_out)
+        hp = hist._p() if hist is not None else None
+        check(self._lib.aeth_fir_exec_decim(self.h, hp, x._p(), x.n, out._p(), out.n))
+        return out
+
     def filter_file(self, in_path, out_path, chunk=0):
         """raw cf32 file -> FIR -> raw cf32 file (util::file format), through the double-buffered pipeline."""
         import os

@@ -79,6 +79,17 @@ class Qpsk(_Modulation):
     table = GENERIC_QPSK_TABLE
 
 
+def table(ctx, symbols):
+    """Any implementor of trait Modulation backed by a table of 2^k symbols, k = 1 .. 8: the trait's default
+    index / modulate / demod_naive (modulation.rs:94-149)."""
+    symbols = np.ascontiguousarray(symbols, np.complex64)
+    k = int(symbols.size).bit_length() - 1
+    if symbols.size != 1 << k or not 1 <= k <= 8:
+        raise ValueError("a symbol table holds 2, 4, ... 256 entries")
+    cls = type(f"Table{symbols.size}", (_Modulation,), {"BITS_PER_SYMBOL": k})
+    return cls(ctx, symbols)
+
+
 def bpsk(ctx):                                                  # modulation.rs:61-63
     return Bpsk(ctx)
 

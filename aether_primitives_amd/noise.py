@@ -25,6 +25,38 @@ class Awgn:
         return signal
 
 
+    def fill(self, target):                  # noise.rs:61-65 (capacity = the vector's length)
+        check(self._lib.aeth_awgn_fill(self.ctx.h, target._p(), target.n, self.power, self.seed, self.offset))
+        self.offset += target.n
+        return target
+
+    def iter(self, chunk=4096):              # noise.rs:67-84: an endless stream of next()
+        """Generator of cf32 noise samples, drawn from the device `chunk` at a time."""
+        buf = self.ctx.empty(chunk)
+        while True:
+            for v in self.fill(buf).to_host():
+                yield v
+
+
+def philox4x32_10(ctx, counters, keys):
+    """The generator's integer stage on the device: counters (n, 4) and keys (n, 2) uint32 -> (n, 4) uint32."""
+    import ctypes as C
+    c = np.ascontiguousarray(counters, np.uint32).reshape(-1, 4); k = np.ascontiguousarray(keys, np.uint32).reshape(-1, 2)
+    n = c.shape[0]
+    ck = np.ascontiguousarray(np.concatenate([c, k], axis=1))
+    lib = _lib.load()
+    din, dout = C.c_void_p(), C.c_void_p()
+    check(lib.aeth_dev_alloc(ctx.h, ck.nbytes, C.byref(din))); check(lib.aeth_dev_alloc(ctx.h, 16 * n, C.byref(dout)))
+    try:
+        check(lib.aeth_upload(ctx.h, din, ck.ctypes.data_as(C.c_void_p), ck.nbytes))
+        check(lib.aeth_rng_philox4x32_10(ctx.h, din, n, dout))
+        out = np.empty((n, 4), np.uint32)
+        check(lib.aeth_download(ctx.h, out.ctypes.data_as(C.c_void_p), dout, out.nbytes))
+    finally:
+        lib.aeth_dev_free(ctx.h, din); lib.aeth_dev_free(ctx.h, dout)
+    return out
+
+
 def generator(ctx):                          # noise.rs:8-11
     return Awgn(ctx, 1.0, DEFAULT_RNG_SEED)
 

@@ -121,6 +121,11 @@ AETH_API int aeth_vec_zero  (aeth_ctx *ctx, aeth_cf32 *self_, size_t n);        
  * (the `chunks_mut(fft_len).for_each(|c| c.vec_rfft(..).vec_mirror())` idiom,
  * src/util/plot.rs:59-61) */
 AETH_API int aeth_vec_mirror_frames(aeth_ctx *ctx, aeth_cf32 *self_, size_t frame_len, size_t batch);
+/* vec_mul with ONE right-hand side shared by `batch` consecutive frames of `frame_len` (frames[f][j] *= sig[j]):
+ * the middle step of `c.vec_rfft(..).vec_mul(&sig).vec_rifft(..)` over chunks_mut(fft_len)
+ * (benches/benches.rs:410-416); n_sig != frame_len -> AETH_E_LEN with the reference's text (:100-104) */
+AETH_API int aeth_vec_mul_frames(aeth_ctx *ctx, aeth_cf32 *frames, size_t frame_len, size_t batch,
+                                 const aeth_cf32 *sig, size_t n_sig);
 /* vec_mutate (:179-182) takes a Rust closure and stays on the host side of the binding. */
 
 /* ---- VecOps, host-slice flavour (synchronous) ----------------------------- */
@@ -153,6 +158,11 @@ AETH_API const char *aeth_fft_algorithm(const aeth_fft *plan);
  * `in` and must equal batch*len ("Input and FFT must be the same length"). */
 AETH_API int aeth_fft_exec(aeth_fft *plan, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out,
                            size_t batch, int sign, int scale_kind, float x);
+/* The same followed by vec_mirror on every frame (`chunks_mut(fft_len).for_each(|c| c.vec_rfft(&mut fft, s)
+ * .vec_mirror())`, src/util/plot.rs:59-61): for the register-resident power-of-two lengths the swap of the halves
+ * is folded into the transform's store addresses (no second pass over memory), other lengths run the two steps. */
+AETH_API int aeth_fft_exec_mirrored(aeth_fft *plan, const aeth_cf32 *in_dev, size_t n_in, aeth_cf32 *out_dev,
+                                    size_t batch, int sign, int scale_kind, float x);
 /* host slices, one frame per call: the literal trait methods. out may equal in. */
 AETH_API int aeth_fft_exec_host(aeth_fft *plan, const aeth_cf32 *in, size_t n_in,
                                 aeth_cf32 *out, size_t n_out, int sign, int scale_kind, float x);
@@ -186,6 +196,11 @@ AETH_API size_t aeth_fir_hop(const aeth_fir *fir);      /* outputs per block (<=
  * ntaps-1 samples preceding in_dev[0] (x[-(ntaps-1)] .. x[-1]).  out != in. */
 AETH_API int aeth_fir_exec(aeth_fir *fir, const aeth_cf32 *hist_dev, const aeth_cf32 *in_dev,
                            size_t n, aeth_cf32 *out_dev);
+/* The filter followed by sampling::downsample (src/sampling.rs:28-42) in one pass: out[i] = y[i * dec] with
+ * dec = n / n_out.  n % n_out != 0 -> AETH_E_ARG "Only even decimations are supported" (:32-36).  Bit-identical
+ * to aeth_fir_exec + aeth_downsample; the output write traffic drops by dec.  fft_len 1024 .. 4096. */
+AETH_API int aeth_fir_exec_decim(aeth_fir *fir, const aeth_cf32 *hist_dev, const aeth_cf32 *in_dev, size_t n,
+                                 aeth_cf32 *out_dev, size_t n_out);
 AETH_API int aeth_fir_exec_host(aeth_fir *fir, const aeth_cf32 *hist_host, const aeth_cf32 *in_host,
                                 size_t n, aeth_cf32 *out_host);
 
@@ -259,6 +274,15 @@ AETH_API int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym_dev, size_t ns
  * offset += n, as the reference's generator object would. */
 AETH_API int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal_dev, size_t n, float power, uint64_t seed,
                              uint64_t offset);
+/* Awgn::fill / Awgn::iter (src/noise.rs:61-84): target[i] = next() = (z.re * scale, z.im * scale) -- scaled
+ * ONCE, unlike apply -- for positions offset .. offset+n of stream `seed`.  The reference fills a Vec up to its
+ * capacity; here the capacity is `n`. */
+AETH_API int aeth_awgn_fill(aeth_ctx *ctx, aeth_cf32 *target_dev, size_t n, float power, uint64_t seed,
+                            uint64_t offset);
+/* The generator's integer stage by itself (replaces rand::StdRng, src/noise.rs:2-4,23,33): out[i][0..3] =
+ * Philox4x32-10 of counter ctr_key[i][0..3] under key ctr_key[i][4..5] (Salmon et al., SC'11; the Random123
+ * known-answer vectors are in tests/golden/philox4x32_10_kat.json).  Device pointers, n x 6 and n x 4 words. */
+AETH_API int aeth_rng_philox4x32_10(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, uint32_t *out_dev);
 
 #ifdef __cplusplus
 }

@@ -495,8 +495,38 @@ void orc_qpsk_demod_naive(const orc_cf32 *sym, size_t nsym, uint8_t *bits_out)
 /* GENERIC_BPSK_TABLE :77 */
 static const orc_cf32 BPSK[2] = { {1.0f, 1.0f}, {-1.0f, -1.0f} };
 
+/* trait Modulation, DEFAULT methods (modulation.rs:94-149) for a symbol table of 2^bps entries, bps = 3..8 */
+static int orc_modulate_generic(const uint8_t *bits, size_t nbits, int bps, const orc_cf32 *table, orc_cf32 *out)
+{
+    if (!table || nbits % (size_t)bps) return -1;
+    for (size_t s = 0; s < nbits / (size_t)bps; s++) {
+        size_t idx = 0;
+        for (int i = 0; i < bps; i++) idx += ((size_t)bits[s * (size_t)bps + i] % 2) << i;      /* :107-110 */
+        out[s] = table[idx];                                                                    /* :115-121 */
+    }
+    return 0;
+}
+
+static int orc_demod_generic(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *table, int compat, uint8_t *bits_out)
+{
+    if (!table) return -1;
+    int ncand = compat ? bps * 2 : (1 << bps);                                                  /* :135 */
+    if (ncand > (1 << bps)) ncand = 1 << bps;
+    for (size_t s = 0; s < nsym; s++) {
+        int best = 0; float bd = 0;
+        for (int i = 0; i < ncand; i++) {
+            float dr = sym[s].re - table[i].re, di = sym[s].im - table[i].im;                   /* :136 */
+            float d = dr * dr + di * di;                                                        /* :137 */
+            if (i == 0 || d < bd) { best = i; bd = d; }                                         /* :139 first minimum */
+        }
+        for (int i = 0; i < bps; i++) bits_out[s * (size_t)bps + i] = (uint8_t)((best >> i) & 1);   /* :143 */
+    }
+    return 0;
+}
+
 int orc_modulate(const uint8_t *bits, size_t nbits, int bps, const orc_cf32 *table, orc_cf32 *out)
 {
+    if (bps >= 3 && bps <= 8) return orc_modulate_generic(bits, nbits, bps, table, out);
     if (bps != 1 && bps != 2) return -1;
     if (nbits % (size_t)bps) return -1;            /* chunks() would hand index() a short chunk */
     const orc_cf32 *t = table ? table : (bps == 1 ? BPSK : QPSK);
@@ -510,6 +540,7 @@ int orc_modulate(const uint8_t *bits, size_t nbits, int bps, const orc_cf32 *tab
 
 int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *table, int compat, uint8_t *bits_out)
 {
+    if (bps >= 3 && bps <= 8) return orc_demod_generic(sym, nsym, bps, table, compat, bits_out);
     if (bps != 1 && bps != 2) return -1;
     const orc_cf32 *t = table ? table : (bps == 1 ? BPSK : QPSK);
     const int ncand = bps == 1 ? 2 : 4;            /* trait default scans BITS_PER_SYMBOL*2 (:135) = 2 for BPSK */
@@ -535,6 +566,23 @@ int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *t
 #include "awgn_restatement.inc"
 
 void orc_rng_cnormal(uint64_t seed, uint64_t idx, float *re, float *im) { aeth_rng_cnormal(seed, idx, re, im); }
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    aeth_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+/* Awgn::fill (noise.rs:61-65): push next() until the capacity is reached; next() scales once (noise.rs:39-43) */
+void orc_awgn_fill(orc_cf32 *target, size_t n, float power, uint64_t seed, uint64_t offset)
+{
+    const float scale = sqrtf(power);                           /* noise.rs:35 */
+    for (size_t i = 0; i < n; i++) {
+        float zr, zi;
+        aeth_rng_cnormal(seed, offset + i, &zr, &zi);
+        target[i].re = zr * scale;                              /* noise.rs:41 */
+        target[i].im = zi * scale;                              /* noise.rs:42 */
+    }
+}
 
 void orc_awgn_apply(orc_cf32 *signal, size_t n, float power, uint64_t seed, uint64_t offset)
 {

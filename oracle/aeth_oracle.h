@@ -133,6 +133,8 @@ int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *t
 void orc_rng_cnormal(uint64_t seed, uint64_t idx, float *re, float *im);
 /* Awgn::apply: s[i] += (z * scale) * scale, scale = sqrtf(power) (noise.rs:35,41-42,58) */
 void orc_awgn_apply(orc_cf32 *signal, size_t n, float power, uint64_t seed, uint64_t offset);
+void orc_awgn_fill(orc_cf32 *target, size_t n, float power, uint64_t seed, uint64_t offset);   /* noise.rs:61-65 */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 /* ---- deterministic synthetic input (the build's own generator) ---------- */
 /* complex normal, unit power (sigma = 1/sqrt(2) per component), splitmix64 +

@@ -101,6 +101,8 @@ def lib():
             "orc_modulate": (i32, [vp, sz, i32, vp, vp]),
             "orc_demod_naive": (i32, [vp, sz, i32, vp, i32, vp]),
             "orc_awgn_apply": (None, [vp, sz, f32, C.c_uint64, C.c_uint64]),
+            "orc_awgn_fill": (None, [vp, sz, f32, C.c_uint64, C.c_uint64]),
+            "orc_philox4x32_10": (None, [vp, vp, vp]),
             "orc_synth_cnormal": (None, [C.c_uint64, vp, sz]),
             "orc_synth_lowpass_taps": (None, [sz, f64, vp]),
         }
@@ -315,6 +317,15 @@ def demod_naive(sym, bps, table=None, compat=True):
     sym = _c64(sym); out = np.empty(sym.size * bps, np.uint8)
     tp = _p(_c64(table)) if table is not None else None
     lib().orc_demod_naive(_p(sym), sym.size, bps, tp, 1 if compat else 0, _p(out)); return out
+
+
+def awgn_fill(n, power, seed=815, offset=0):
+    t = np.empty(n, np.complex64); lib().orc_awgn_fill(_p(t), n, float(np.float32(power)), int(seed), int(offset)); return t
+
+
+def philox4x32_10(counter, key):
+    c = np.ascontiguousarray(counter, np.uint32); k = np.ascontiguousarray(key, np.uint32); o = np.empty(4, np.uint32)
+    lib().orc_philox4x32_10(c.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p)); return o
 
 
 def awgn_apply(signal, power, seed=815, offset=0):

@@ -49,6 +49,7 @@ extern "C" {
 
     pub fn aeth_vec_scale(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, scale: c_float) -> c_int;
     pub fn aeth_vec_mul(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
+    pub fn aeth_vec_mul_frames(ctx: *mut aeth_ctx, frames: *mut cf32, frame_len: usize, batch: usize, sig: *const cf32, n_sig: usize) -> c_int;
     pub fn aeth_vec_div(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
     pub fn aeth_vec_conj(ctx: *mut aeth_ctx, s: *mut cf32, n: usize) -> c_int;
     pub fn aeth_vec_add(ctx: *mut aeth_ctx, s: *mut cf32, n: usize, o: *const cf32, no: usize) -> c_int;
@@ -78,6 +79,7 @@ extern "C" {
                              scale_kind: c_int, x: c_float, view: *mut *const cf32) -> c_int;
     pub fn aeth_fft_exec(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, batch: usize,
                          sign: c_int, scale_kind: c_int, x: c_float) -> c_int;
+    pub fn aeth_fft_exec_mirrored(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, batch: usize, sign: c_int, kind: c_int, x: c_float) -> c_int;
     pub fn aeth_fft_exec_host(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, n_out: usize,
                               sign: c_int, scale_kind: c_int, x: c_float) -> c_int;
     pub fn aeth_fft_exec_tmp_host(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, sign: c_int,
@@ -89,6 +91,7 @@ extern "C" {
                            out: *mut *mut aeth_fir) -> c_int;
     pub fn aeth_fir_destroy(fir: *mut aeth_fir) -> c_int;
     pub fn aeth_fir_exec(fir: *mut aeth_fir, hist: *const cf32, inp: *const cf32, n: usize, out: *mut cf32) -> c_int;
+    pub fn aeth_fir_exec_decim(fir: *mut aeth_fir, hist: *const cf32, inp: *const cf32, n: usize, out: *mut cf32, n_out: usize) -> c_int;
     pub fn aeth_fir_exec_host(fir: *mut aeth_fir, hist: *const cf32, inp: *const cf32, n: usize, out: *mut cf32) -> c_int;
     pub fn aeth_fir_ntaps(fir: *const aeth_fir) -> usize;
     pub fn aeth_fir_fft_len(fir: *const aeth_fir) -> usize;
@@ -115,6 +118,8 @@ extern "C" {
     pub fn aeth_demod_naive(ctx: *mut aeth_ctx, sym: *const cf32, nsym: usize, bits_per_symbol: c_int,
                             table: *const cf32, bits_out: *mut u8, nbits_out: usize, compat: c_int) -> c_int;
     pub fn aeth_awgn_apply(ctx: *mut aeth_ctx, signal: *mut cf32, n: usize, power: c_float, seed: u64, offset: u64) -> c_int;
+    pub fn aeth_awgn_fill(ctx: *mut aeth_ctx, target: *mut cf32, n: usize, power: c_float, seed: u64, offset: u64) -> c_int;
+    pub fn aeth_rng_philox4x32_10(ctx: *mut aeth_ctx, ctr_key: *const u32, n: usize, out: *mut u32) -> c_int;
     pub fn aeth_host_downsample(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void,
                                 n_dst: usize, elem_size: usize) -> c_int;
 }

@@ -46,7 +46,8 @@ def test_bad_arguments(ctx):
     assert lib.aeth_vec_scale(ctx.h, C.c_void_p(v.ptr + 4), 1, 1.0) == _lib.E_ALIGN
     assert b"aligned" in lib.aeth_last_error()
     assert lib.aeth_downsample(ctx.h, v._p(), 64, v._p(), 8, 3) == _lib.E_ARG           # elem_size 3
-    assert lib.aeth_modulate(ctx.h, v._p(), 4, 3, None, v._p(), 1) == _lib.E_UNSUPPORTED
+    assert lib.aeth_modulate(ctx.h, v._p(), 4, 3, None, v._p(), 1) == _lib.E_ARG          # 3 bits per symbol: needs a table
+    assert lib.aeth_modulate(ctx.h, v._p(), 9, 9, v._p(), v._p(), 1) == _lib.E_UNSUPPORTED  # 9 bits per symbol
     with pytest.raises(ap.AetherError):
         Fir(ctx, np.zeros(0, np.complex64), 64)
     with pytest.raises(ap.AetherError):

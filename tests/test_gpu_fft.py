@@ -260,3 +260,18 @@ def test_c5_full_size_properties(ctx, oracle):
         assert bits_equal(Y[fr], oracle.interpolate(X[fr * n:(fr + 1) * n], nb))
     assert bits_equal(np.ascontiguousarray(Y[:, ::nb + 1].real), np.ascontiguousarray(X.reshape(frames, n).real))
     assert bits_equal(np.ascontiguousarray(Y[:, -1]), np.ascontiguousarray(X.reshape(frames, n)[:, -1]))
+
+
+@pytest.mark.parametrize("n,batch", [(2, 5), (4, 3), (16, 100), (64, 33), (256, 7), (512, 9), (1024, 5), (2048, 17), (4096, 3), (8192, 2),
+                                     (100, 6), (1536, 4), (65536, 2)])
+def test_fft_with_mirror_epilogue(ctx, n, batch):
+    """c.vec_rfft(fft, s).vec_mirror() per frame (util/plot.rs:59-61) in one call: bit-identical to the two steps"""
+    x = rand_c64(n, n * batch)
+    f = HipFft(ctx, n, max_batch=batch)
+    two = ctx.vec(x); f.ifwd(two, Scale.SN); two.vec_mirror_frames(n)
+    one = ctx.vec(x); f.rfft_mirror(one, Scale.SN)
+    assert bits_equal(one.to_host(), two.to_host())
+    o = ctx.empty(n * batch)
+    f.rfft_mirror(ctx.vec(x), Scale.NONE, out=o)
+    t = ctx.vec(x); f.ifwd(t, Scale.NONE); t.vec_mirror_frames(n)
+    assert bits_equal(o.to_host(), t.to_host())

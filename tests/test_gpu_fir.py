@@ -165,12 +165,27 @@ def test_correlator_chain(ctx, oracle, n):
         f.mul_chain(d, ctx.vec(sig[:-1]))
 
 
-def test_correlator_chain_generic_length(ctx, oracle):
-    n = 100
-    frames = rand_c64(1, n * 4); sig = rand_c64(2, n)
-    f = HipFft(ctx, n)
+@pytest.mark.parametrize("n,batch", [(100, 4), (100, 5000), (12, 70001), (8192, 9), (6000, 130)])
+def test_correlator_chain_generic_length(ctx, oracle, n, batch):
+    """lengths the fused kernel does not cover: fft -> ONE broadcast multiply launch -> ifft, any batch"""
+    frames = rand_c64(1, n * batch); sig = rand_c64(2, n)
+    f = HipFft(ctx, n, max_batch=batch)
     d = ctx.vec(frames); f.mul_chain(d, ctx.vec(sig))
     assert oracle.evm_db(d.to_host(), oracle.correlate_frames(sig, frames)) <= TOL_DB
+
+
+@pytest.mark.parametrize("n,batch", [(1, 1), (7, 3), (100, 4096), (2048, 513), (300, 70000)])
+def test_vec_mul_frames_bit_exact(ctx, oracle, n, batch):
+    """frames[f] *= sig in one launch == vec_mul frame by frame (vecops.rs:99-112), bit for bit"""
+    frames = rand_c64(3, n * batch); sig = rand_c64(4, n)
+    got = ctx.vec(frames).vec_mul_frames(ctx.vec(sig)).to_host()
+    exp = (frames.reshape(batch, n).copy())
+    for f in range(min(batch, 64)):                       # the oracle frame by frame on a sample of frames ...
+        assert bits_equal(got.reshape(batch, n)[f], oracle.vec_mul(exp[f], sig))
+    tiled = oracle.vec_mul(frames, np.tile(sig, batch))   # ... and the whole thing against one long vec_mul
+    assert bits_equal(got, tiled)
+    with pytest.raises(AssertionError, match="Vectors must have same length"):
+        ctx.vec(frames).vec_mul_frames(ctx.vec(np.concatenate([sig, sig[:1]])), frame_len=n)
 
 
 @pytest.mark.parametrize("n,chunk", [(1000, 1984), (1984 * 7 + 5, 1984 * 2), (3_000_000, 1 << 20), (1 << 23, 0)])
@@ -182,3 +197,26 @@ def test_host_stream_pipeline_bit_identical(ctx, taps, n, chunk):
     y, st = f.filter_stream(x, chunk=chunk)
     assert bits_equal(y, f.filter(x))
     assert st["samples"] == n and st["chunks"] >= 1 and st["seconds"] > 0
+
+
+@pytest.mark.parametrize("n,dec", [(1984 * 4, 2), (30720, 30), (1 << 20, 8), (3_000_000, 3), (123456, 64), (1 << 24, 16)])
+def test_fir_decimating_store(ctx, oracle, taps, n, dec):
+    """aeth_fir_exec_decim == fir -> sampling::downsample (sampling.rs:28-42), bit for bit, one launch"""
+    from aether_primitives_amd import sampling
+    x = rand_c64(n % 1000 + dec, n)
+    f = Fir(ctx, taps, 2048)
+    d = ctx.vec(x)
+    full = f.filter(d)
+    ref = sampling.downsample(ctx, full, ctx.empty(n // dec))
+    got = f.filter_decim(d, dec)
+    assert got.n == n // dec and bits_equal(got.to_host(), ref.to_host())
+    # nothing past the decimated output was touched
+    guard = ctx.vec(np.full(n // dec + 8, 7 - 7j, np.complex64))
+    f.filter_decim(d, dec, out=guard.slice(0, n // dec))
+    assert (guard.to_host()[n // dec:] == 7 - 7j).all()
+
+
+def test_fir_decim_rejects_uneven(ctx, taps):
+    f = Fir(ctx, taps, 2048)
+    with pytest.raises(ap.AetherError, match="Only even decimations"):
+        f.filter_decim(ctx.vec(rand_c64(1, 7000)), 3, out=ctx.empty(2333))       # 7000 % 2333 != 0

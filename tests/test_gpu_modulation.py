@@ -80,6 +80,92 @@ def test_awgn_stream_continues_and_statistics(ctx, oracle):
     assert not bits_equal(other.to_host(), h[:16])                      # different seed, different stream
 
 
+@pytest.mark.parametrize("bps", [3, 4, 6, 8])
+def test_generic_tables_follow_the_trait_defaults(ctx, oracle, bps):
+    """trait Modulation's default methods for any table type (modulation.rs:94-149): 8-PSK, 16/64/256-QAM-like
+    tables; modulate is a gather, demod_naive scans BITS_PER_SYMBOL*2 candidates in compat mode (:135) and all of
+    them otherwise; bit i of the index goes to output byte i (:143)."""
+    rng = np.random.default_rng(bps)
+    m = 1 << bps
+    tab = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+    mod = modulation.table(ctx, tab)
+    assert mod.bits_per_symbol() == bps
+    nsym = 50_003
+    bits = rng.integers(0, 256, nsym * bps, dtype=np.uint8)          # any byte: index() takes bit % 2 (:109)
+    tx = mod.modulate(bits)
+    assert bits_equal(tx.to_host(), oracle.modulate(bits, bps, tab))
+    noisy = (tx.to_host() + 0.05 * (rng.standard_normal(nsym) + 1j * rng.standard_normal(nsym))).astype(np.complex64)
+    for compat in (True, False):
+        got = mod.demod_naive(ctx.vec(noisy), compat=compat).to_host()
+        assert (got == oracle.demod_naive(noisy, bps, tab, compat=compat)).all()
+    # with every candidate scanned and little noise the transmitted bits come back
+    back = mod.demod_naive(ctx.vec(tx.to_host()), compat=False).to_host()
+    assert (back == (bits % 2)).all()
+    with pytest.raises(ap.LengthMismatch):
+        mod.modulate(np.zeros(bps + 1, np.uint8))
+
+
+def test_philox_known_answers_on_the_device(ctx, oracle):
+    """The generator's integer stage as the GPU runs it, against the Random123 known-answer vectors (fixture) and,
+    on random counters/keys, against the oracle's independent restatement."""
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "philox4x32_10_kat.json")))["cases"]
+    ctr = np.array([[int(x, 16) for x in c["counter"]] for c in kat], np.uint32)
+    key = np.array([[int(x, 16) for x in c["key"]] for c in kat], np.uint32)
+    got = noise.philox4x32_10(ctx, ctr, key)
+    for g, c in zip(got, kat):
+        assert [f"{v:08x}" for v in g] == c["expected"], c["name"]
+    rng = np.random.default_rng(5)
+    ctr = rng.integers(0, 2 ** 32, (5000, 4), dtype=np.uint64).astype(np.uint32)
+    key = rng.integers(0, 2 ** 32, (5000, 2), dtype=np.uint64).astype(np.uint32)
+    got = noise.philox4x32_10(ctx, ctr, key)
+    for i in range(0, 5000, 37):
+        assert (got[i] == oracle.philox4x32_10(ctr[i], key[i])).all()
+
+
+@pytest.mark.parametrize("n,offset", [(1, 0), (2, 1), (7, 0), (4097, 3), (1 << 20, 1 << 33)])
+def test_awgn_fill_bit_exact(ctx, oracle, n, offset):
+    """Awgn::fill / iter (noise.rs:61-84): next() scaled once; stream positions continue across calls"""
+    for power in (1.0, 0.01):
+        g = noise.new(ctx, power, 815); g.offset = offset
+        d = ctx.vec(np.full(n + 1, 9 + 9j, np.complex64))
+        g.fill(d.slice(1, n + 1))                                    # 8- but not 16-byte aligned
+        h = d.to_host()
+        assert h[0] == 9 + 9j and bits_equal(h[1:], oracle.awgn_fill(n, power, 815, offset))
+        assert g.offset == offset + n
+    it = noise.new(ctx, 0.5, 7).iter(chunk=64)
+    first = np.array([next(it) for _ in range(150)], np.complex64)  # crosses two chunk boundaries
+    assert bits_equal(first, oracle.awgn_fill(150, 0.5, 7, 0))
+
+
+def test_awgn_distribution_ks_and_tails(ctx):
+    """2 x 2^24 normals from the device generator: Kolmogorov-Smirnov against N(0,1), tail counts beyond 3, 4 and
+    5 sigma inside 5-sigma binomial bands, the Box-Muller radius against chi-square(2), and no serial correlation."""
+    from scipy import stats
+    n = 1 << 24
+    z = noise.new(ctx, 1.0, 20261004).fill(ctx.empty(n)).to_host()
+    v = np.concatenate([z.real, z.imag]).astype(np.float64)
+    assert np.isfinite(v).all()
+    d, _ = stats.kstest(v[::4], "norm")                              # 8.4 M values: sorting all 33 M adds nothing
+    assert d < 1.36 / np.sqrt(v.size / 4) * 1.5                      # 5 % critical value, with headroom for f32 rounding
+    for k in (3.0, 4.0, 5.0):
+        p = 2 * stats.norm.sf(k)
+        cnt = int((np.abs(v) > k).sum())
+        exp, sd = v.size * p, np.sqrt(v.size * p * (1 - p))
+        assert abs(cnt - exp) <= 5 * sd + 1, (k, cnt, exp)
+    assert np.abs(v).max() < 6.2                                      # 24-bit uniforms: |z| <= sqrt(2 ln 2^24) = 5.77
+    r2 = (z.real.astype(np.float64) ** 2 + z.imag.astype(np.float64) ** 2)[::8]
+    d2, _ = stats.kstest(r2, "chi2", args=(2,))
+    assert d2 < 1.36 / np.sqrt(r2.size) * 1.5
+    ph = np.angle(z[::8].astype(np.complex128))
+    d3, _ = stats.kstest((ph + np.pi) / (2 * np.pi), "uniform")
+    assert d3 < 1.36 / np.sqrt(ph.size) * 1.5
+    x = z.real[: 1 << 22].astype(np.float64)
+    for lag in (1, 2, 3, 64):
+        assert abs(np.corrcoef(x[:-lag], x[lag:])[0, 1]) < 5 / np.sqrt(x.size)
+    assert abs(np.corrcoef(z.real[: 1 << 22], z.imag[: 1 << 22])[0, 1]) < 5 / np.sqrt(1 << 22)
+
+
 def test_c4_chain(ctx, oracle):
     """QPSK mod -> AWGN (power 0.01, examples/modem.rs:25) -> per 2048-frame rfft * conj-reference
     -> rifft -> hard demod.  Correlating against a unit impulse reference leaves the frame

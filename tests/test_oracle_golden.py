@@ -188,3 +188,25 @@ def test_synth_is_deterministic(oracle):
     assert bits_equal(a, b) and not bits_equal(a, oracle.synth_cnormal(816, 4096))
     p = float(np.mean(np.abs(a.astype(np.complex128)) ** 2))
     assert 0.9 < p < 1.1
+
+
+def test_philox4x32_10_known_answers(oracle):
+    """The oracle's Philox4x32-10 (the integer stage of the AWGN generator) against the Random123 distribution's
+    own known-answer vectors: zero, all-ones and pi-digits counter/key sets."""
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "philox4x32_10_kat.json")))
+    assert len(kat["cases"]) >= 3
+    for c in kat["cases"]:
+        got = oracle.philox4x32_10([int(x, 16) for x in c["counter"]], [int(x, 16) for x in c["key"]])
+        assert [f"{v:08x}" for v in got] == c["expected"], c["name"]
+
+
+def test_awgn_fill_scales_once_apply_twice(oracle):
+    """noise.rs:39-43 (next: one scaling) vs :53-59 (apply: next().scale(sc), a second one)"""
+    import numpy as np
+    z = np.zeros(1000, np.complex64)
+    f = oracle.awgn_fill(1000, 0.25, 815, 0)
+    a = oracle.awgn_apply(z, 0.25, 815, 0)
+    assert np.allclose(a, f * np.float32(0.5), rtol=1e-6)           # sqrt(0.25) once more
+    one = oracle.awgn_fill(1000, 1.0, 815, 0)
+    assert np.array_equal(oracle.awgn_apply(z, 1.0, 815, 0).view(np.uint32), one.view(np.uint32))
