@@ -710,11 +710,10 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_POW2) rc = plan_pow2(p);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_MIXED) rc = plan_mixed(p);
     if (rc == AETH_OK && p->algo == aeth::FFT_ALGO_RAGGED) rc = aeth::fft_plan_ragged(p);
-    if (rc == AETH_OK) rc = aeth::fft_ensure_tmp(p, 2 * len * max_batch);
-    if (rc == AETH_OK) {
-        hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * len * sizeof(float2), hipHostMallocDefault);
-        if (e != hipSuccess) rc = aeth::hip_fail(e, "hipHostMalloc");
-    }
+    // Cfft.tmp (fft.rs:141,155) is allocated on first use: only tfwd/tbwd and the host-slice flavours lend or stage
+    // through it, and the sub-plans of the four-step / chirp-z paths and the FIR's plan never do (a 2^24-point child
+    // would otherwise hold 256 MiB of device and 256 MiB of pinned host memory for nothing)
+    (void)max_batch;
     if (rc != AETH_OK) { aeth_fft_destroy(p); return rc; }
     *out = p;
     return AETH_OK;
@@ -737,6 +736,18 @@ int aeth_fft_destroy(aeth_fft *p)
 
 size_t aeth_fft_len(const aeth_fft *p) { return p ? p->len : 0; }
 const char *aeth_fft_algorithm(const aeth_fft *p) { return p ? p->algo_name : ""; }
+
+// device temp of >= elems and (host = true) the pinned 2*len mirror tfwd/tbwd lend out
+static int ensure_temps(aeth_fft *p, size_t elems, bool host)
+{
+    aeth::DeviceGuard g(p->ctx->device);
+    int rc = aeth::fft_ensure_tmp(p, elems); if (rc) return rc;
+    if (host && !p->tmp_host) {
+        hipError_t e = hipHostMalloc((void **)&p->tmp_host, 2 * p->len * sizeof(float2), hipHostMallocDefault);
+        if (e != hipSuccess) return aeth::hip_fail(e, "hipHostMalloc");
+    }
+    return AETH_OK;
+}
 
 static int check_exec(const aeth_fft *p, int sign, int kind)
 {
@@ -801,6 +812,8 @@ int aeth_fft_exec_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 
     AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
     AETH_REQUIRE(n_out == p->len, AETH_E_LEN, "Output and FFT must be the same length");
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
+    rc = ensure_temps(p, 2 * p->len, false); if (rc) return rc;
+    aeth::DeviceGuard dev_guard(p->ctx->device);
     hipStream_t st = aeth::ctx_stream(p->ctx);
     const size_t bytes = p->len * sizeof(float2);
     AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));   /* tmp[..len] <- input, fft.rs:168 */
@@ -819,6 +832,8 @@ int aeth_fft_exec_tmp_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, int si
     *view = nullptr;
     AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
     AETH_REQUIRE(in, AETH_E_ARG, "null pointer");
+    rc = ensure_temps(p, 2 * p->len, true); if (rc) return rc;
+    aeth::DeviceGuard dev_guard(p->ctx->device);
     hipStream_t st = aeth::ctx_stream(p->ctx);
     const size_t bytes = p->len * sizeof(float2);
     AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));

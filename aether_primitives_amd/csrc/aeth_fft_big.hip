@@ -137,11 +137,11 @@ __global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_rows(const cf
 }
 
 template <class C, int S>
-int launch_cols(aeth_fft *plan, const float2 *in, size_t batch)
+int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_total)
 {
     constexpr int G = group_of<C>();
     const size_t grid = batch * (plan->n2 / G);
-    const bool nt = aeth::streams_past_cache(plan->len * batch * sizeof(float2) * 4 / 3);   // from 96 MiB: x, a and X together pass the cache
+    const bool nt = aeth::streams_past_cache(plan->len * batch_total * sizeof(float2) * 4 / 3);   // from 96 MiB: x, a and X together pass the cache
     auto kern = nt ? fourstep_cols<C, S, true> : fourstep_cols<C, S, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
@@ -151,11 +151,11 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch)
 }
 
 template <class C, int S>
-int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale)
+int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale, size_t batch_total)
 {
     constexpr int G = group_of<C>();
     const size_t grid = batch * (plan->n1 / G);
-    const bool nt = aeth::streams_past_cache(plan->len * batch * sizeof(float2) * 4 / 3);
+    const bool nt = aeth::streams_past_cache(plan->len * batch_total * sizeof(float2) * 4 / 3);
     auto kern = nt ? fourstep_rows<C, S, true> : fourstep_rows<C, S, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)plan->work_dev, (cf *)out, (const cf *)plan->sub2->tw_lane_dev, (int)plan->n1,
@@ -370,21 +370,38 @@ int fft_plan_fourstep(aeth_fft *plan)
 
 int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch, int sign, float scale)
 {
-    int rc = ensure_work(plan, plan->len * batch);
+    // Measured and not kept (tools/tune_4step.py, AETH_4S_GROUP_MIB; profiles/r02_c5.json): running steps A and B
+    // group by group through a work buffer of one cache-sized group, so that the intermediate is overwritten in the
+    // Infinity Cache instead of travelling to HBM -- 512 x 65536: 176 us as two launches, 185 / 202 / 222 / 308 us
+    // with groups of 128 / 64 / 32 / 16 MiB.  Each of the two launches already streams at copy speed (537 MB in
+    // 88 us) and part of the intermediate is served from the cache as it is; more launches only add their gaps.
+    // The knob stays for the tuning tool: 0 = one group (default).
+    const size_t gmib = (size_t)aeth::tuning_int("AETH_4S_GROUP_MIB", 0);
+    size_t gf = gmib ? gmib * ((size_t)1 << 20) / (plan->len * sizeof(float2)) : batch;
+    if (gf < 1) gf = 1;
+    if (gf > batch) gf = batch;
+    int rc = ensure_work(plan, plan->len * gf);
     if (rc) return rc;
+    for (size_t g0 = 0; g0 < batch; g0 += gf) {
+        const size_t cnt = batch - g0 < gf ? batch - g0 : gf;
+        const float2 *gin = in + g0 * plan->len;
+        float2 *gout = out + g0 * plan->len;
 #define AETH_BODY(NN)                                                                                   \
-    return sign > 0 ? launch_cols<typename CfgFor<NN>::type, +1>(plan, in, batch)                       \
-                    : launch_cols<typename CfgFor<NN>::type, -1>(plan, in, batch)
-    auto cols = [&]() -> int { AETH_POW2_SWITCH(plan->n1, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n1")) };
+    return sign > 0 ? launch_cols<typename CfgFor<NN>::type, +1>(plan, gin, cnt, batch)                 \
+                    : launch_cols<typename CfgFor<NN>::type, -1>(plan, gin, cnt, batch)
+        auto cols = [&]() -> int { AETH_POW2_SWITCH(plan->n1, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n1")) };
 #undef AETH_BODY
 #define AETH_BODY(NN)                                                                                   \
-    return sign > 0 ? launch_rows<typename CfgFor<NN>::type, +1>(plan, out, batch, scale)               \
-                    : launch_rows<typename CfgFor<NN>::type, -1>(plan, out, batch, scale)
-    auto rows = [&]() -> int { AETH_POW2_SWITCH(plan->n2, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n2")) };
+    return sign > 0 ? launch_rows<typename CfgFor<NN>::type, +1>(plan, gout, cnt, scale, batch)         \
+                    : launch_rows<typename CfgFor<NN>::type, -1>(plan, gout, cnt, scale, batch)
+        auto rows = [&]() -> int { AETH_POW2_SWITCH(plan->n2, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n2")) };
 #undef AETH_BODY
-    rc = cols();
-    if (rc) return rc;
-    return rows();
+        rc = cols();
+        if (rc) return rc;
+        rc = rows();
+        if (rc) return rc;
+    }
+    return AETH_OK;
 }
 
 // ------------------------------- four-step, any two factors ----------------------------

@@ -59,27 +59,44 @@ int aeth_file_write(const char *path, const void *src, size_t n, size_t elem_siz
 int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_path, size_t chunk, aeth_pipe_stats *stats)
 {
     AETH_REQUIRE(fir && in_path && out_path, AETH_E_ARG, "null argument");
-    size_t n = 0;
-    int rc = aeth_file_count_structs(in_path, sizeof(aeth_cf32), &n);
-    if (rc) return rc;
-    int fo = open(out_path, O_RDWR | O_CREAT | O_TRUNC, 0644);
-    AETH_REQUIRE(fo >= 0, AETH_E_ARG, "%s: %s", out_path, strerror(errno));
-    if (n == 0) { close(fo); if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0}; return AETH_OK; }
-    const size_t bytes = n * sizeof(aeth_cf32);
+    if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0};
+    // the input is opened, measured and mapped BEFORE the output is created or truncated, and a path that names
+    // the same file twice is refused: truncating the recording before reading it would filter zeros
     int fi = open(in_path, O_RDONLY);
-    void *mi = MAP_FAILED, *mo = MAP_FAILED;
-    if (fi < 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", in_path, strerror(errno));
-    if (rc == AETH_OK && ftruncate(fo, (off_t)bytes) != 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", out_path, strerror(errno));
-    if (rc == AETH_OK) {
-        mi = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fi, 0);
-        mo = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fo, 0);
-        if (mi == MAP_FAILED || mo == MAP_FAILED) rc = aeth::set_error(AETH_E_NOMEM, "mmap: %s", strerror(errno));
+    AETH_REQUIRE(fi >= 0, AETH_E_ARG, "%s: %s", in_path, strerror(errno));
+    struct stat si;
+    if (fstat(fi, &si) != 0) { int e = errno; close(fi); return aeth::set_error(AETH_E_ARG, "%s: %s", in_path, strerror(e)); }
+    struct stat so;
+    if (stat(out_path, &so) == 0 && so.st_dev == si.st_dev && so.st_ino == si.st_ino) {
+        close(fi);
+        return aeth::set_error(AETH_E_ARG, "%s and %s are the same file: the FIR cannot run in place", in_path, out_path);
     }
-    if (rc == AETH_OK) rc = aeth_fir_stream_host(fir, (const aeth_cf32 *)mi, n, (aeth_cf32 *)mo, chunk, stats);
+    if ((size_t)si.st_size % sizeof(aeth_cf32) != 0) {
+        close(fi);
+        return aeth::set_error(AETH_E_LEN, "%s: %lld bytes is not a whole number of cf32 samples", in_path, (long long)si.st_size);
+    }
+    const size_t n = (size_t)si.st_size / sizeof(aeth_cf32);
+    const size_t bytes = n * sizeof(aeth_cf32);
+    void *mi = MAP_FAILED, *mo = MAP_FAILED;
+    int rc = AETH_OK;
+    if (n > 0) {
+        mi = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fi, 0);
+        if (mi == MAP_FAILED) { int e = errno; close(fi); return aeth::set_error(AETH_E_NOMEM, "mmap %s: %s", in_path, strerror(e)); }
+    }
+    int fo = open(out_path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fo < 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", out_path, strerror(errno));
+    if (rc == AETH_OK && n > 0) {
+        if (ftruncate(fo, (off_t)bytes) != 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", out_path, strerror(errno));
+        if (rc == AETH_OK) {
+            mo = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fo, 0);
+            if (mo == MAP_FAILED) rc = aeth::set_error(AETH_E_NOMEM, "mmap %s: %s", out_path, strerror(errno));
+        }
+        if (rc == AETH_OK) rc = aeth_fir_stream_host(fir, (const aeth_cf32 *)mi, n, (aeth_cf32 *)mo, chunk, stats);
+    }
     if (mi != MAP_FAILED) munmap(mi, bytes);
     if (mo != MAP_FAILED) { msync(mo, bytes, MS_SYNC); munmap(mo, bytes); }
-    if (fi >= 0) close(fi);
-    close(fo);
+    close(fi);
+    if (fo >= 0) close(fo);
     return rc;
 }
 

@@ -346,6 +346,7 @@ int aeth_fir_exec_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, 
     if (n == 0) return AETH_OK;
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
     aeth_ctx *ctx = f->ctx;
+    aeth::DeviceGuard dev_guard(ctx->device);
     const size_t nh = f->ntaps - 1;
     const size_t bytes = n * sizeof(float2);
     int rc = aeth::ctx_stage(ctx, 0, (n + nh) * sizeof(float2)); if (rc) return rc;

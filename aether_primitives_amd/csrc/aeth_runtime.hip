@@ -3,6 +3,7 @@
 // keeps implicit in Rust ownership (Vec<cf32>, Cfft.tmp: src/fft.rs:134-159).
 #include "aeth_internal.h"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -211,7 +212,21 @@ int aeth_ctx_sync(aeth_ctx *ctx)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
     aeth::DeviceGuard g(ctx->device);
-    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));       // the join puts the aux lane in front of this wait
+    hipStream_t s = aeth::ctx_stream(ctx);                       // the join puts the aux lane in front of this wait
+    // Short waits are polled: the wake-up latency of a blocking wait is a visible share of a millisecond-long
+    // batch of launches.  After AETH_SYNC_SPIN_US (tuning; default 2000) the blocking wait takes over.
+    const int spin_us = aeth::tuning_int("AETH_SYNC_SPIN_US", 2000);
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) return AETH_OK;
+            if (q != hipErrorNotReady) return aeth::hip_fail(q, "hipStreamQuery");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+        }
+        (void)hipGetLastError();                                 // hipErrorNotReady is not an error
+    }
+    AETH_HIP(hipStreamSynchronize(s));
     return AETH_OK;
 }
 

@@ -13,7 +13,8 @@ pub mod ffi;
 use aether_primitives::cf32;
 use aether_primitives::fft::{Fft, Scale};
 use ffi::*;
-use std::os::raw::c_void;
+use std::marker::PhantomData;
+use std::os::raw::{c_int, c_void};
 use std::ptr;
 
 fn scale_args(s: Scale) -> (i32, f32) {
@@ -45,15 +46,18 @@ impl Context {
 }
 impl Drop for Context { fn drop(&mut self) { unsafe { aeth_ctx_destroy(self.h); } } }
 
-/// Replaces `Cfft` (src/fft.rs:134-235).
-pub struct HipFft { h: *mut aeth_fft }
-unsafe impl Send for HipFft {}
-impl HipFft {
+/// Replaces `Cfft` (src/fft.rs:134-235).  Borrows its `Context` for `'c`: the plan's Drop (and every call)
+/// goes through the context's stream, so the context must outlive it -- the borrow checker enforces what the
+/// C side requires.  Not `Send`: the plan shares the context's one stream and staging buffers with every other
+/// object of that context, so it stays on the context's thread (the reference's `Cfft` is `Send` because it owns
+/// everything it touches; a whole `Context` with its plans can still move as one unit).
+pub struct HipFft<'c> { h: *mut aeth_fft, _ctx: PhantomData<&'c Context> }
+impl<'c> HipFft<'c> {
     /// `Cfft::with_len` (src/fft.rs:147)
-    pub fn with_len(ctx: &Context, len: usize) -> HipFft {
+    pub fn with_len(ctx: &'c Context, len: usize) -> HipFft<'c> {
         let mut h = ptr::null_mut();
         check(unsafe { aeth_fft_create(ctx.h, len, 1, &mut h) });
-        HipFft { h }
+        HipFft { h, _ctx: PhantomData }
     }
     fn host(&mut self, input: *const cf32, n_in: usize, output: *mut cf32, n_out: usize, sign: i32, s: Scale) {
         let (k, x) = scale_args(s);
@@ -67,9 +71,9 @@ impl HipFft {
         unsafe { std::slice::from_raw_parts(view, self.len()) }
     }
 }
-impl Drop for HipFft { fn drop(&mut self) { unsafe { aeth_fft_destroy(self.h); } } }
+impl<'c> Drop for HipFft<'c> { fn drop(&mut self) { unsafe { aeth_fft_destroy(self.h); } } }
 
-impl Fft for HipFft {
+impl<'c> Fft for HipFft<'c> {
     fn fwd(&mut self, input: &[cf32], output: &mut [cf32], s: Scale) {
         self.host(input.as_ptr(), input.len(), output.as_mut_ptr(), output.len(), AETH_SIGN_REF_FWD, s)
     }
@@ -153,13 +157,13 @@ pub mod sampling {
 
 /// Overlap-save FIR behind `fir::Fir`'s constructor shape (src/fir.rs:3-22 stores taps and a scratch but has
 /// no filter method; this one filters).
-pub struct Fir { h: *mut aeth_fir }
-unsafe impl Send for Fir {}
-impl Fir {
-    pub fn new(ctx: &Context, taps: &[cf32], fft_len: usize) -> Fir {
+/// Like `HipFft`, borrows its `Context` (Drop goes through the context) and stays on the context's thread.
+pub struct Fir<'c> { h: *mut aeth_fir, _ctx: PhantomData<&'c Context> }
+impl<'c> Fir<'c> {
+    pub fn new(ctx: &'c Context, taps: &[cf32], fft_len: usize) -> Fir<'c> {
         let mut h = ptr::null_mut();
         check(unsafe { aeth_fir_create(ctx.h, taps.as_ptr(), taps.len(), fft_len, &mut h) });
-        Fir { h }
+        Fir { h, _ctx: PhantomData }
     }
     /// device-resident stream: y[n] = sum_k taps[k] x[n-k], zero initial state
     pub fn filter(&mut self, x: &DeviceVec, y: &mut DeviceVec) {
@@ -174,7 +178,7 @@ impl Fir {
         st
     }
 }
-impl Drop for Fir { fn drop(&mut self) { unsafe { aeth_fir_destroy(self.h); } } }
+impl<'c> Drop for Fir<'c> { fn drop(&mut self) { unsafe { aeth_fir_destroy(self.h); } } }
 
 /// `modulation::Modulation` for the generic BPSK/QPSK tables (src/modulation.rs:5-149) on device buffers,
 /// and `noise::Awgn::apply` (src/noise.rs:53-59).

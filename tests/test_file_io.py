@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from helpers import bits_equal, rand_c64
+import aether_primitives_amd as ap
 
 
 def test_binary_roundtrip_and_struct_count(tmp_path):
@@ -41,3 +42,22 @@ def test_file_to_file_fir(ctx, oracle, tmp_path):
     y = ap.file.binary_reader(pout).read_vec(x.size)
     assert bits_equal(y, f.filter(x))
     assert oracle.evm_db(y, oracle.fir_ols_f32(taps, x, 2048, f.hop, threads=4)) <= -120
+
+
+@pytest.mark.gpu
+def test_file_fir_refuses_to_run_in_place(ctx, oracle, tmp_path):
+    """in_path == out_path (also through a hard link) must not truncate the recording"""
+    import os
+    from aether_primitives_amd import Fir
+    x = (np.arange(5000) + 1j).astype(np.complex64)
+    p = tmp_path / "iq.bin"; x.tofile(p)
+    link = tmp_path / "same.bin"; os.link(p, link)
+    f = Fir(ctx, oracle.synth_lowpass_taps(64, 0.25), 2048)
+    for out in (p, link):
+        with pytest.raises(ap.AetherError, match="same file"):
+            f.filter_file(str(p), str(out))
+        assert np.array_equal(np.fromfile(p, np.complex64), x)          # untouched
+    bad = tmp_path / "odd.bin"; bad.write_bytes(b"\0" * 13)
+    with pytest.raises(ap.AetherError):
+        f.filter_file(str(bad), str(tmp_path / "o.bin"))
+    assert not (tmp_path / "o.bin").exists()                              # nothing created for a bad input

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import aether_primitives_amd as ap
-from aether_primitives_amd import Scale, sampling
+from aether_primitives_amd import Scale, sampling, HipFft
 from helpers import bits_equal, rand_c64
 
 pytestmark = pytest.mark.gpu
@@ -164,3 +164,20 @@ def test_downsample_source_beyond_4gib(ctx, oracle):
         hi = min(lo + 300, n_dst)
         want = pat[(np.arange(lo, hi) * dec) % P]
         assert bits_equal(dst.slice(lo, hi).to_host(), want), lo
+
+
+@pytest.mark.parametrize("logn", [23, 24])
+def test_fourstep_largest_lengths(ctx, oracle, logn):
+    """2^23 and 2^24 points (n2 = 4096: the Cfg<4096> column / row kernels with 2 columns per workgroup) in place and
+    out of place against the f64 truth (advertised but untested)."""
+    n = 1 << logn
+    x = rand_c64(logn, n)
+    f = HipFft(ctx, n)
+    assert f.algorithm == "fourstep_pow2"
+    truth = np.fft.ifft(x.astype(np.complex128)) * np.sqrt(float(n))      # reference fwd = +j exponent; Scale::SN
+    d = ctx.vec(x); f.ifwd(d, Scale.SN)
+    assert oracle.evm_db(d.to_host(), truth) <= -120
+    o = ctx.empty(n); f.fwd(ctx.vec(x), o, Scale.SN)
+    assert bits_equal(o.to_host(), d.to_host())
+    back = ctx.vec(d.to_host()); f.ibwd(back, Scale.SN)
+    assert oracle.evm_db(back.to_host(), x) <= -120
