@@ -69,6 +69,7 @@ PROTOTYPES = {
     "aeth_fft_algorithm": (C.c_char_p, [vp]),
     "aeth_fft_exec": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
     "aeth_fft_exec_mirrored": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
+    "aeth_fft_exec_interpolate": (i32, [vp, vp, sz, sz, i32, i32, f32, vp, sz, sz, i32, psz]),
     "aeth_fft_exec_host": (i32, [vp, vp, sz, vp, sz, i32, i32, f32]),
     "aeth_fft_exec_tmp_host": (i32, [vp, vp, sz, i32, i32, f32, pvp]),
     "aeth_fft_exec_tmp": (i32, [vp, vp, sz, sz, i32, i32, f32, pvp]),

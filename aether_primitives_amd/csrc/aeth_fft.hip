@@ -788,6 +788,28 @@ int aeth_fft_exec_mirrored(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_c
     return aeth_vec_mirror_frames(p->ctx, out, p->len, batch);              /* vecops.rs:157-161 per frame */
 }
 
+/* per frame: c.vec_rfft / vec_rifft (sign, scale) then sampling::interpolate(&c, &mut dst, n_between) (sampling.rs:7-24);
+ * `in` is left as it was */
+int aeth_fft_exec_interpolate(aeth_fft *p, const aeth_cf32 *in, size_t n_in, size_t batch, int sign, int kind, float x,
+                              aeth_cf32 *dst, size_t dst_cap, size_t n_between, int compat_im, size_t *n_written)
+{
+    if (n_written) *n_written = 0;
+    int rc = check_exec(p, sign, kind); if (rc) return rc;
+    AETH_REQUIRE(n_in == batch * p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);     /* fft.rs:163-167 */
+    AETH_REQUIRE(p->len > 0, AETH_E_LEN, "interpolate on an empty src (the reference panics: sampling.rs:23)");
+    if (batch == 0) return AETH_OK;
+    AETH_REQUIRE(in && dst, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(dst), AETH_E_ALIGN, "pointer not 8-byte aligned");
+    AETH_REQUIRE(n_between < 0x7fffffffu, AETH_E_ARG, "n_between too large");
+    const size_t Lo = p->len + (p->len - 1) * n_between;
+    AETH_REQUIRE(dst_cap >= Lo * batch, AETH_E_LEN, "dst capacity %zu < %zu", dst_cap, Lo * batch);
+    const float s = aeth_scale_factor(kind, p->len, x);
+    // the two steps through the plan's temp (Cfft.tmp, fft.rs:141); a fused last pass was measured slower (aeth_fft_big.hip)
+    rc = ensure_temps(p, n_in, false); if (rc) return rc;
+    rc = aeth::fft_run(p, (const float2 *)in, p->tmp_dev, batch, sign, s); if (rc) return rc;
+    return aeth_interpolate_frames(p->ctx, (const aeth_cf32 *)p->tmp_dev, p->len, batch, dst, dst_cap, n_between, compat_im, n_written);
+}
+
 int aeth_fft_exec_tmp(aeth_fft *p, const aeth_cf32 *in, size_t n_in, size_t batch, int sign, int kind, float x,
                       const aeth_cf32 **view)
 {

@@ -136,6 +136,16 @@ __global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_rows(const cf
     }
 }
 
+// ---- step B fused with sampling::interpolate: built, measured, NOT kept (round 2; profiles/r02_c5.json) -------------
+// BASELINE config 5 is `frame.vec_rfft(fft, s)` then `sampling::interpolate(&frame, &mut dst, 9)`.  A kernel that
+// transforms G rows plus the next one (X[i+1] of the row group's last element), transposes through LDS as step B does
+// and writes the interpolated runs of G*(nb+1) outputs per k2 instead of X was bit-identical to the two calls and
+// saves 16 of the chain's 104 B/sample -- but ran the chain (512 x 65536, nb = 9) in 875 us (1058 with per-output index
+// divisions, 1231 with descriptor-masked stores) against 653 us for the two kernels: the output phase writes 327 KB
+// per workgroup from 272 lanes that first had to transform 17 rows (41 KiB of LDS, 3 workgroups per CU), and a
+// store-bound kernel wants the 32 KiB per CU in flight that aeth_sampling.hip's interpolate_kernel32 has (6.4 TB/s).
+// aeth_fft_exec_interpolate therefore runs the two steps through the plan's temp.
+
 template <class C, int S>
 int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_total)
 {

@@ -112,6 +112,15 @@ class HipFft:
                                                SIGN_REF_FWD, s.kind, s.x))
         return out
 
+    def rfft_interpolate(self, frames, dst, n_between, s=Scale.NONE, compat_im=True):
+        """every frame: vec_rfft(self, s), then sampling::interpolate(frame, dst, n_between) (sampling.rs:7-24) appended
+        frame after frame into dst; `frames` stays as it was.  Returns the number of samples written."""
+        n = self.len()
+        w = C.c_size_t(0)
+        check(self._lib.aeth_fft_exec_interpolate(self.h, frames._p(), frames.n, frames.n // n if n else 0, SIGN_REF_FWD,
+                                                  s.kind, s.x, dst._p(), dst.n, n_between, 1 if compat_im else 0, C.byref(w)))
+        return w.value
+
     def _tmp(self, inp, sign, s):
         view = C.c_void_p()
         if _is_dev(inp):

@@ -232,10 +232,16 @@ def side_workload(args):
         f = ap.HipFft(ctx, 65536, max_batch=max(frames, 1))
         nbuf = 2 if frames > 128 else 3
         bufs = [(ctx.vec(synth_stream(815 + lo + 7919 * i, n)), ctx.empty((65536 + 65535 * nb) * frames)) for i in range(nbuf)]
-        def step(i):
-            a, o = bufs[i % nbuf]; f.ifwd(a, Scale.SN); sampling.interpolate(ctx, a, o, nb, frame_len=65536)
+        if args.c5_unfused:
+            def step(i):                                        # the two trait-level calls, spectrum through HBM
+                a, o = bufs[i % nbuf]; f.ifwd(a, Scale.SN); sampling.interpolate(ctx, a, o, nb, frame_len=65536)
+        else:
+            def step(i):                                        # one call (spectrum through the plan's temp)
+                a, o = bufs[i % nbuf]; f.rfft_interpolate(a, o, nb, Scale.SN)
         job_samples = 65536 * total_frames
-        name, bytes_ = "C5: 512 x 65536-point FFT (Scale::SN) + 10x linear interpolation, frame-sharded", 104 * n
+        name = "C5: 512 x 65536-point FFT (Scale::SN) + 10x linear interpolation, frame-sharded" + (
+            " (two calls)" if args.c5_unfused else " (aeth_fft_exec_interpolate)")
+        bytes_ = 104 * n
         shard = f"frame_shard: rank 0 owns frames [{lo}, {lo + frames}) of {total_frames}"
     else:
         n_channels, frames = 8, 4096
@@ -303,6 +309,7 @@ def main():
                           "the previous one to drain; this is also the mode to profile per-kernel durations in")
     ap_.add_argument("--no-single-queue-leg", action="store_true",
                      help="skip the extra leg that repeats the timed steps on one queue (per-launch kernel time)")
+    ap_.add_argument("--c5-unfused", action="store_true", help="--workload c5 as two calls (fft, then interpolate)")
     ap_.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],
                      help="c3 (default) = the headline config; the others are BASELINE configs 2, 4, 5 for the record")
     args = ap_.parse_args()

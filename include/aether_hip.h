@@ -163,6 +163,12 @@ AETH_API int aeth_fft_exec(aeth_fft *plan, const aeth_cf32 *in, size_t n_in, aet
  * is folded into the transform's store addresses (no second pass over memory), other lengths run the two steps. */
 AETH_API int aeth_fft_exec_mirrored(aeth_fft *plan, const aeth_cf32 *in_dev, size_t n_in, aeth_cf32 *out_dev,
                                     size_t batch, int sign, int scale_kind, float x);
+/* Per frame: the transform, then sampling::interpolate(&frame, &mut dst, n_between) (src/sampling.rs:7-24) -- BASELINE
+ * config 5's chain in one call.  dst receives batch frames of len + (len-1)*n_between samples; `in` is not modified.
+ * The spectrum goes through the plan's temp (Cfft.tmp); bit-identical to aeth_fft_exec + aeth_interpolate_frames. */
+AETH_API int aeth_fft_exec_interpolate(aeth_fft *plan, const aeth_cf32 *in_dev, size_t n_in, size_t batch, int sign,
+                                       int scale_kind, float x, aeth_cf32 *dst_dev, size_t dst_cap, size_t n_between,
+                                       int compat_im, size_t *n_written);
 /* host slices, one frame per call: the literal trait methods. out may equal in. */
 AETH_API int aeth_fft_exec_host(aeth_fft *plan, const aeth_cf32 *in, size_t n_in,
                                 aeth_cf32 *out, size_t n_out, int sign, int scale_kind, float x);

@@ -80,6 +80,8 @@ extern "C" {
     pub fn aeth_fft_exec(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, batch: usize,
                          sign: c_int, scale_kind: c_int, x: c_float) -> c_int;
     pub fn aeth_fft_exec_mirrored(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, batch: usize, sign: c_int, kind: c_int, x: c_float) -> c_int;
+    pub fn aeth_fft_exec_interpolate(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, batch: usize, sign: c_int, kind: c_int, x: c_float,
+                                     dst: *mut cf32, dst_cap: usize, n_between: usize, compat_im: c_int, n_written: *mut usize) -> c_int;
     pub fn aeth_fft_exec_host(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, out: *mut cf32, n_out: usize,
                               sign: c_int, scale_kind: c_int, x: c_float) -> c_int;
     pub fn aeth_fft_exec_tmp_host(plan: *mut aeth_fft, inp: *const cf32, n_in: usize, sign: c_int,

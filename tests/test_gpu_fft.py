@@ -275,3 +275,23 @@ def test_fft_with_mirror_epilogue(ctx, n, batch):
     f.rfft_mirror(ctx.vec(x), Scale.NONE, out=o)
     t = ctx.vec(x); f.ifwd(t, Scale.NONE); t.vec_mirror_frames(n)
     assert bits_equal(o.to_host(), t.to_host())
+
+
+@pytest.mark.parametrize("n,batch,nb", [(65536, 3, 9), (65536, 1, 1), (16384, 5, 4), (32768, 2, 2), (131072, 2, 9), (262144, 1, 3),
+                                        (2048, 4, 9), (100, 3, 2), (524288, 1, 1)])
+def test_fft_then_interpolate_in_one_call(ctx, n, batch, nb):
+    """BASELINE config 5's chain in one call: per frame vec_rfft(Scale::SN) then sampling::interpolate
+    (sampling.rs:7-24); bit-identical to the two calls, input left untouched."""
+    from aether_primitives_amd import sampling
+    x = rand_c64(n + nb, n * batch)
+    f = HipFft(ctx, n, max_batch=batch)
+    Lo = n + (n - 1) * nb
+    for compat in (True, False):
+        two_x = ctx.vec(x); f.ifwd(two_x, Scale.SN)
+        two = ctx.empty(Lo * batch); sampling.interpolate(ctx, two_x, two, nb, frame_len=n, compat_im=compat)
+        src = ctx.vec(x)
+        one = ctx.vec(np.full(Lo * batch + 3, 5 - 5j, np.complex64))
+        wrote = f.rfft_interpolate(src, one.slice(0, Lo * batch), nb, Scale.SN, compat_im=compat)
+        h = one.to_host()
+        assert wrote == Lo * batch and bits_equal(h[:Lo * batch], two.to_host())
+        assert (h[Lo * batch:] == 5 - 5j).all() and bits_equal(src.to_host(), x)      # nothing past dst, input untouched
