@@ -34,7 +34,7 @@ static const int NBUF = 6;
 struct Variant {
     const char *name;
     int var;          // kernel template VAR
-    int mode;         // 0 plain launch, 1 hipExtAnyOrderLaunch, 2 two streams alternating
+    int mode;         // 0 plain launch, 1 hipExtAnyOrderLaunch, 2 two streams alternating, 3 the same with the library's event protocol
     int grid;         // 0 = default
 };
 
@@ -110,6 +110,7 @@ int main(int argc, char **argv)
         {"x2", 1000, 0, 512}, {"x2/nomem", 1048, 0, 512}, {"x2/nolds+nomem", 1176, 0, 512},
         {"base/g1280", 0, 0, 1280}, {"base/g1536", 0, 0, 1536}, {"base/g2048", 0, 0, 2048}, {"base/g3072", 0, 0, 3072}, {"base/g4229", 0, 0, 4229}, {"base/g8457", 0, 0, 8457},
         {"base/g2048/2q", 0, 2, 2048}, {"base/g4229/2q", 0, 2, 4229},
+        {"prio/2q+events", 4, 3, 0}, {"base/2q+events", 0, 3, 0},
         {"nolds/2q", 128, 2, 0}, {"prio/2q", 4, 2, 0}, {"peel/2q", 1, 2, 0},
         {"nomem", 48, 0, 0}, {"nomem/g768", 48, 0, 768}, {"nomem/g512", 48, 0, 512}, {"nomem/g256", 48, 0, 256},
     };
@@ -175,9 +176,17 @@ int main(int argc, char **argv)
         a.s_fwd = 1.0f; a.s_bwd = 1.0f; a.frame_n = 2048;
         return a;
     };
+    hipEvent_t ev_pre[2];
+    CK(hipEventCreateWithFlags(&ev_pre[0], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ev_pre[1], hipEventDisableTiming));
+    CK(hipEventRecord(ev_pre[0], s0)); CK(hipEventRecord(ev_pre[1], s1));
     auto issue = [&](const Variant &v, int i) {
         const int grid = v.grid ? v.grid : cap;
-        hipStream_t s = (v.mode == 2 && (i & 1)) ? s1 : s0;
+        const int lane = (v.mode >= 2 && (i & 1)) ? 1 : 0;
+        hipStream_t s = lane ? s1 : s0;
+        if (v.mode == 3) {       // aeth_runtime.hip: ctx_fir_lane -- wait for the other lane's history, record this lane's
+            CK(hipStreamWaitEvent(s, ev_pre[1 - lane], 0));
+            CK(hipEventRecord(ev_pre[lane], s));
+        }
         launch(v.var, args_for(i % NBUF), grid, s, v.mode == 1);
     };
     auto sync_all = [&] { CK(hipStreamSynchronize(s0)); CK(hipStreamSynchronize(s1)); };
