@@ -48,16 +48,24 @@ template <class C> constexpr int group_of()
     return g;
 }
 
+// columns per workgroup of step A: GW wanted (16 = 128-byte segments, 32 = 256-byte), fewer when lanes or LDS run out
+template <class C, int GW> constexpr int col_group_of()
+{
+    int g = GW;
+    while (g > 1 && (g * C::T > 1024 || g * col_stride<C>() * 8 > AETH_4S_LDS_LIMIT)) g /= 2;
+    return g;
+}
+
 // ---- step A: G columns per workgroup ---------------------------------------------
 // NT: x is read / X is written with the non-temporal hint, which leaves L2 and the Infinity Cache to the
 // intermediate (batch 512 x 65536: 212 -> 159 us); small batches that fit the cache whole do better without
-template <class C0, int S, bool NT>
-__global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_cols(const cf *in, cf *work,
+template <class C0, int S, bool NT, int GW = 16>
+__global__ __launch_bounds__((col_group_of<C0, GW>()) * C0::T) void fourstep_cols(const cf *in, cf *work,
                                                                           const cf *__restrict__ twL1,
                                                                           const cf *__restrict__ twN, int N2, size_t N)
 {
     using C = OneImage<C0>;
-    constexpr int G = group_of<C0>();
+    constexpr int G = col_group_of<C0, GW>();
     constexpr int CS = col_stride<C0>();
     __shared__ cf lds_all[G * CS > 0 ? G * CS : 1];
     const int col = threadIdx.x % G;
@@ -149,10 +157,14 @@ __global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_rows(const cf
 template <class C, int S>
 int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_total)
 {
-    constexpr int G = group_of<C>();
-    const size_t grid = batch * (plan->n2 / G);
     const bool nt = aeth::streams_past_cache(plan->len * batch_total * sizeof(float2) * 4 / 3);   // from 96 MiB: x, a and X together pass the cache
-    auto kern = nt ? fourstep_cols<C, S, true> : fourstep_cols<C, S, false>;
+    // 32 adjacent columns per workgroup (256-byte segments) where lanes and LDS allow (n1 <= 256): 512 x 65536 runs in
+    // 169 us against 177 us with 16 (tools/tune_4step.py, AETH_4S_COLG), no difference on small batches
+    const bool wide = aeth::tuning_int("AETH_4S_COLG", 32) >= 32 && col_group_of<C, 32>() == 32 && plan->n2 % 32 == 0;
+    const int G = wide ? 32 : col_group_of<C, 16>();
+    const size_t grid = batch * (plan->n2 / G);
+    auto kern = wide ? (nt ? fourstep_cols<C, S, true, 32> : fourstep_cols<C, S, false, 32>)
+                     : (nt ? fourstep_cols<C, S, true, 16> : fourstep_cols<C, S, false, 16>);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
                        aeth::tuning_int("AETH_4S_NOTW", 0) ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);

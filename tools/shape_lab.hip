@@ -42,6 +42,55 @@ __global__ __launch_bounds__(128) void walk(const float2 *in, float2 *out, long 
     }
 }
 
+// SPLIT variant: the next block's 16 loads and this block's 16 stores issued in Q groups spread over the block's
+// (artificial) latency instead of two bursts
+template <int Q, int AL, int AS, int SPIN>
+__global__ __launch_bounds__(128) void walk_split(const float2 *in, float2 *out, long long nblocks)
+{
+    u32x2 cur[16], nxt[16];
+    const int tid = threadIdx.x;
+    auto rsrc_in = [&](long long b) {
+        const int bytes = b < nblocks ? 16384 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in + (b < nblocks ? b : 0) * 2048), 0, bytes, 0x00020000);
+    };
+    {
+        auto rs = rsrc_in(blockIdx.x);
+#pragma unroll
+        for (int m = 0; m < 16; m++) nxt[m] = __builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * 128) * 8, 0, AL);
+    }
+    for (long long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) cur[m] = nxt[m];
+        auto ri = rsrc_in(b + gridDim.x);
+        auto ro = __builtin_amdgcn_make_buffer_rsrc(out + b * 2048, 0, 16384, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+#pragma unroll
+            for (int m = q * (16 / Q); m < (q + 1) * (16 / Q); m++) nxt[m] = __builtin_amdgcn_raw_buffer_load_b64(ri, (tid + m * 128) * 8, 0, AL);
+            if (SPIN) __builtin_amdgcn_s_sleep(SPIN / Q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = q * (16 / Q); m < (q + 1) * (16 / Q); m++) __builtin_amdgcn_raw_buffer_store_b64(cur[m], ro, (tid + m * 128) * 8, 0, AS);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// one block per workgroup, no loop (what the hardware dispatcher does with the same bytes)
+template <int AL, int AS>
+__global__ __launch_bounds__(128) void oneshot(const float2 *in, float2 *out, long long nblocks)
+{
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.x;
+    auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in + b * 2048), 0, 16384, 0x00020000);
+    auto ro = __builtin_amdgcn_make_buffer_rsrc(out + b * 2048, 0, 16384, 0x00020000);
+    u32x2 v[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = __builtin_amdgcn_raw_buffer_load_b64(ri, (tid + m * 128) * 8, 0, AL);
+#pragma unroll
+    for (int m = 0; m < 16; m++) __builtin_amdgcn_raw_buffer_store_b64(v[m], ro, (tid + m * 128) * 8, 0, AS);
+}
+
 template <class F> float timeit(F f)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -78,5 +127,18 @@ int main()
     RUN(1, 2, 18, 64, 1024, 0) RUN(1, 2, 18, 64, 1024, 1) RUN(2, 2, 18, 64, 1024, 0) RUN(2, 2, 18, 64, 1024, 1)
     RUN(1, 2, 18, 120, 1024, 0) RUN(1, 2, 18, 120, 1024, 1) RUN(2, 2, 18, 120, 1024, 0) RUN(2, 2, 18, 120, 1024, 1) RUN(3, 2, 18, 120, 1024, 1)
     RUN(1, 2, 2, 0, 1024, 0) RUN(1, 0, 18, 0, 1024, 0) RUN(1, 2, 18, 0, 1024, 0)
+#define RUNS(Q, SPIN, TWOQ)                                                                                           \
+    {                                                                                                                 \
+        float ms = timeit([&](int i) { walk_split<Q, 2, 18, SPIN><<<1024, 128, 0, (TWOQ && (i & 1)) ? s2 : 0>>>(A[i % NB], B[i % NB], nblocks); }); \
+        (void)hipStreamSynchronize(s2);                                                                               \
+        printf("split %d  sleep %3d  grid 1024  %s : %6.1f us  %6.1f GB/s\n", Q, SPIN, TWOQ ? "2q" : "1q", ms * 1e3, 2.0 * bytes / ms / 1e6); \
+    }
+    RUNS(1, 120, 0) RUNS(2, 120, 0) RUNS(4, 120, 0) RUNS(8, 120, 0) RUNS(16, 120, 0)
+    RUNS(1, 120, 1) RUNS(4, 120, 1) RUNS(16, 120, 1)
+    RUNS(1, 0, 0) RUNS(4, 0, 0) RUNS(16, 0, 0)
+    {
+        float ms = timeit([&](int i) { oneshot<2, 18><<<(unsigned)nblocks, 128>>>(A[i % NB], B[i % NB], nblocks); });
+        printf("one block per workgroup, %lld workgroups : %6.1f us  %6.1f GB/s\n", nblocks, ms * 1e3, 2.0 * bytes / ms / 1e6);
+    }
     return 0;
 }

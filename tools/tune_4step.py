@@ -16,7 +16,7 @@ if "--" in args:
     i = args.index("--"); variants = args[i + 1:] or [""]; args = args[:i]
 batch = int(args[0]) if len(args) > 0 else 512
 N = int(args[1]) if len(args) > 1 else 65536
-KEYS = ["AETH_4S_NOTW", "AETH_4S_GROUP_MIB"]
+KEYS = ["AETH_4S_NOTW", "AETH_4S_GROUP_MIB", "AETH_4S_COLG"]
 
 def setenv(v):
     for k in KEYS: os.environ.pop(k, None)
