@@ -328,6 +328,7 @@ int aeth_event_record(aeth_event *ev)
 int aeth_event_sync(aeth_event *ev)
 {
     AETH_REQUIRE(ev, AETH_E_ARG, "event is null");
+    aeth::DeviceGuard g(ev->ctx->device);
     AETH_HIP(hipEventSynchronize(ev->ev));
     return AETH_OK;
 }
@@ -335,6 +336,7 @@ int aeth_event_sync(aeth_event *ev)
 int aeth_event_elapsed_ms(aeth_event *start, aeth_event *stop, float *ms)
 {
     AETH_REQUIRE(start && stop && ms, AETH_E_ARG, "null argument");
+    aeth::DeviceGuard g(start->ctx->device);
     AETH_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
     return AETH_OK;
 }

@@ -91,6 +91,48 @@ __global__ __launch_bounds__(128) void oneshot(const float2 *in, float2 *out, lo
     for (int m = 0; m < 16; m++) __builtin_amdgcn_raw_buffer_store_b64(v[m], ro, (tid + m * 128) * 8, 0, AS);
 }
 
+// the same 16 KiB blocks with 16-byte accesses: 8 per lane at a stride of 2 KiB (persistent, next block prefetched)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int AL, int AS, int SPIN>
+__global__ __launch_bounds__(128) void walk16(const float4 *in, float4 *out, long long nblocks)
+{
+    u32x4 cur[8], nxt[8];
+    const int tid = threadIdx.x;
+    auto rsrc_in = [&](long long b) {
+        const int bytes = b < nblocks ? 16384 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(in + (b < nblocks ? b : 0) * 1024), 0, bytes, 0x00020000);
+    };
+    {
+        auto rs = rsrc_in(blockIdx.x);
+#pragma unroll
+        for (int m = 0; m < 8; m++) nxt[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + m * 128) * 16, 0, AL);
+    }
+    for (long long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) cur[m] = nxt[m];
+        auto ri = rsrc_in(b + gridDim.x);
+        auto ro = __builtin_amdgcn_make_buffer_rsrc(out + b * 1024, 0, 16384, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < 8; m++) nxt[m] = __builtin_amdgcn_raw_buffer_load_b128(ri, (tid + m * 128) * 16, 0, AL);
+        if (SPIN) __builtin_amdgcn_s_sleep(SPIN);
+#pragma unroll
+        for (int m = 0; m < 8; m++) __builtin_amdgcn_raw_buffer_store_b128(cur[m], ro, (tid + m * 128) * 16, 0, AS);
+    }
+}
+template <int AL, int AS>
+__global__ __launch_bounds__(128) void oneshot16(const float4 *in, float4 *out, long long nblocks)
+{
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.x;
+    auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(in + b * 1024), 0, 16384, 0x00020000);
+    auto ro = __builtin_amdgcn_make_buffer_rsrc(out + b * 1024, 0, 16384, 0x00020000);
+    u32x4 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = __builtin_amdgcn_raw_buffer_load_b128(ri, (tid + m * 128) * 16, 0, AL);
+#pragma unroll
+    for (int m = 0; m < 8; m++) __builtin_amdgcn_raw_buffer_store_b128(v[m], ro, (tid + m * 128) * 16, 0, AS);
+}
+
 template <class F> float timeit(F f)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -139,6 +181,20 @@ int main()
     {
         float ms = timeit([&](int i) { oneshot<2, 18><<<(unsigned)nblocks, 128>>>(A[i % NB], B[i % NB], nblocks); });
         printf("one block per workgroup, %lld workgroups : %6.1f us  %6.1f GB/s\n", nblocks, ms * 1e3, 2.0 * bytes / ms / 1e6);
+    }
+#define RUN16(SPIN, TWOQ)                                                                                             \
+    {                                                                                                                 \
+        float ms = timeit([&](int i) { walk16<2, 18, SPIN><<<1024, 128, 0, (TWOQ && (i & 1)) ? s2 : 0>>>((const float4 *)A[i % NB], (float4 *)B[i % NB], nblocks); }); \
+        (void)hipStreamSynchronize(s2);                                                                               \
+        printf("16-byte lanes (8 per lane)  sleep %3d  grid 1024  %s : %6.1f us  %6.1f GB/s\n", SPIN, TWOQ ? "2q" : "1q", ms * 1e3, 2.0 * bytes / ms / 1e6); \
+    }
+    RUN16(0, 0) RUN16(0, 1) RUN16(120, 0) RUN16(120, 1)
+    RUN(1, 2, 18, 0, 1024, 0) RUN(1, 2, 18, 120, 1024, 1)
+    {
+        float ms = timeit([&](int i) { oneshot16<2, 18><<<(unsigned)nblocks, 128>>>((const float4 *)A[i % NB], (float4 *)B[i % NB], nblocks); });
+        printf("one block per workgroup, 16-byte lanes : %6.1f us  %6.1f GB/s\n", ms * 1e3, 2.0 * bytes / ms / 1e6);
+        ms = timeit([&](int i) { oneshot<2, 18><<<(unsigned)nblocks, 128>>>(A[i % NB], B[i % NB], nblocks); });
+        printf("one block per workgroup,  8-byte lanes : %6.1f us  %6.1f GB/s\n", ms * 1e3, 2.0 * bytes / ms / 1e6);
     }
     return 0;
 }
