@@ -25,6 +25,7 @@
 #include "aeth_fft_core.h"
 #include "aeth_fft_plan.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -553,6 +554,14 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
 // ================================ planning ====================================
 bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
 
+size_t largest_prime_factor(size_t n)
+{
+    size_t best = 1;
+    for (size_t f = 2; f * f <= n; f++)
+        while (n % f == 0) { best = f; n /= f; }
+    return n > 1 ? n : best;
+}
+
 // radix schedule for stockham_mixed: 8s and 4s first, then 2, 3, 5, 7, other primes
 bool factorize_mixed(size_t n, std::vector<int> &fac)
 {
@@ -690,6 +699,13 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     } else if (aeth::fft_ragged_supported(len) && !aeth::tuning_int("AETH_FFT_NORAGGED", 0)) {
         p->algo = aeth::FFT_ALGO_RAGGED;
         p->algo_name = "stockham_mixed_ragged";
+    } else if (2 * len - 1 <= 4096 && largest_prime_factor(len) >= 17 && aeth::tuning_int("AETH_FFT_PRIME_BLU", 1)) {
+        // a prime factor from 17 up and a chirp-z convolution that fits the one-launch kernel (M <= 4096): 1.4-2.6 TB/s
+        // against 0.05-0.7 TB/s through the generic O(r^2) pass of the LDS kernel and 0.4-1.0 TB/s through
+        // fourstep_mixed (tools/prime_route.py: 17 ... 2047, x1.1 ... x50)
+        p->algo = aeth::FFT_ALGO_BLUESTEIN;
+        p->algo_name = "bluestein";
+        rc = aeth::fft_plan_bluestein(p);
     } else if (len <= 8192 && factorize_mixed(len, p->factors)) {      // two LDS images of the frame: 128 KiB at most
         p->algo = aeth::FFT_ALGO_MIXED;
         p->algo_name = "stockham_mixed";

@@ -137,7 +137,8 @@ def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 100).algorithm == "stockham_mixed_ragged"
     assert HipFft(ctx, 126).algorithm == "stockham_mixed_ragged"
     assert HipFft(ctx, 143).algorithm == "stockham_mixed_ragged"
-    assert HipFft(ctx, 323).algorithm == "stockham_mixed"
+    assert HipFft(ctx, 323).algorithm == "bluestein"                 # 17 * 19: one-launch chirp-z beats the O(r^2) prime pass
+    assert HipFft(ctx, 2 * 2057).algorithm == "stockham_mixed"       # 4114 = 2 * 11^2 * 17: too long for the one-launch kernel
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"
     assert HipFft(ctx, 10000).algorithm == "stockham_mixed_ragged"
