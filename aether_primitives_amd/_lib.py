@@ -74,6 +74,7 @@ PROTOTYPES = {
     "aeth_fft_exec_tmp_host": (i32, [vp, vp, sz, i32, i32, f32, pvp]),
     "aeth_fft_exec_tmp": (i32, [vp, vp, sz, sz, i32, i32, f32, pvp]),
     "aeth_fft_mul_ifft": (i32, [vp, vp, sz, sz, vp, sz, i32, f32, i32, f32]),
+    "aeth_fft_mul_ifft_demod": (i32, [vp, vp, sz, sz, vp, sz, i32, f32, i32, f32, i32, vp, vp, sz, i32]),
     "aeth_fir_create": (i32, [vp, vp, sz, sz, pvp]),
     "aeth_fir_destroy": (i32, [vp]),
     "aeth_fir_ntaps": (sz, [vp]),
@@ -93,6 +94,7 @@ PROTOTYPES = {
     "aeth_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
     "aeth_host_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
     "aeth_modulate": (i32, [vp, vp, sz, i32, vp, vp, sz]),
+    "aeth_modulate_awgn": (i32, [vp, vp, sz, i32, vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
     "aeth_demod_naive": (i32, [vp, vp, sz, i32, vp, vp, sz, i32]),
     "aeth_awgn_apply": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
     "aeth_awgn_fill": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),

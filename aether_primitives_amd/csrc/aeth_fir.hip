@@ -60,6 +60,14 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     // one-frame workgroups run their LDS exchanges at raised wave priority (V_PRIO: -0.3 ... -0.5 us per 16 Mi-sample
     // launch in tools/fir_lab, A/B in one process); the other variants of aeth_fir_kernel.h measured null or negative
     constexpr int VAR = (C::F == 1) ? V_PRIO : 0;
+    if constexpr (C::F == 1) {
+        if (b.bits) {                                       // hard demodulation instead of the sample store
+            if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR | V_DEMOD>), dim3(grid), dim3(C::WG), 0, stream, b);
+            else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false, VAR | V_DEMOD>), dim3(grid), dim3(C::WG), 0, stream, b);
+            AETH_HIP(hipGetLastError());
+            return AETH_OK;
+        }
+    }
     if constexpr (C::F == 1 && !SCALED) {
         if (b.dec.d > 1) {                                  // decimating store (aeth_fir_exec_decim)
             if (nt) hipLaunchKernelGGL((fmi_kernel<C, false, 1, true, false, VAR | V_DECIM>), dim3(grid), dim3(C::WG), 0, stream, b);
@@ -138,6 +146,46 @@ int aeth_fft_mul_ifft(aeth_fft *plan, aeth_cf32 *frames, size_t n_total, size_t 
     a.hop = (int)plan->len; a.ov = 0; a.nhist = 0;
     a.s_fwd = aeth_scale_factor(kind_fwd, plan->len, x_fwd);
     a.s_bwd = aeth_scale_factor(kind_bwd, plan->len, x_bwd);
+    return dispatch_fmi(plan->ctx, plan->len, a);
+}
+
+/* frames.vec_rfft(fft, s).vec_mul(&sig).vec_rifft(fft, s) per frame (benches/benches.rs:410-416), then
+ * Modulation::demod_naive on the result (examples/modem.rs:28-31) -- BASELINE config 4's receive side.  For the
+ * one-frame-per-workgroup lengths the correlator output is demodulated in registers and only the bit bytes are
+ * written (8 B read + bits per sample instead of 8 R + 8 W + 8 R + bits); `frames` is not modified. */
+int aeth_fft_mul_ifft_demod(aeth_fft *plan, const aeth_cf32 *frames, size_t n_total, size_t batch, const aeth_cf32 *sig,
+                            size_t n_sig, int kind_fwd, float x_fwd, int kind_bwd, float x_bwd, int bps,
+                            const aeth_cf32 *table, uint8_t *bits_out, size_t nbits_out, int compat)
+{
+    AETH_REQUIRE(plan, AETH_E_ARG, "plan is null");
+    AETH_REQUIRE(n_total == batch * plan->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
+    AETH_REQUIRE(n_sig == plan->len, AETH_E_LEN, AETH_MSG_VEC_LEN);
+    AETH_REQUIRE(kind_fwd >= 0 && kind_fwd <= 3 && kind_bwd >= 0 && kind_bwd <= 3, AETH_E_ARG, "bad scale kind");
+    AETH_REQUIRE(bps == 1 || bps == 2, AETH_E_UNSUPPORTED, "bits_per_symbol %d: BPSK (1) or QPSK (2)", bps);
+    AETH_REQUIRE(nbits_out == n_total * (size_t)bps, AETH_E_LEN, "output holds %zu bits, input gives %zu", nbits_out, n_total * (size_t)bps);
+    if (batch == 0) return AETH_OK;
+    AETH_REQUIRE(frames && sig && bits_out, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(frames) && aeth::aligned8(sig) && ((uintptr_t)bits_out % (size_t)bps) == 0, AETH_E_ALIGN, "pointer alignment");
+    static const aeth_cf32 kB[2] = {{1.f, 1.f}, {-1.f, -1.f}};                              /* modulation.rs:77 */
+    static const aeth_cf32 kQ[4] = {{1.f, 1.f}, {-1.f, 1.f}, {1.f, -1.f}, {-1.f, -1.f}};    /* modulation.rs:87-92 */
+    const aeth_cf32 *tb = table ? table : (bps == 1 ? kB : kQ);
+    if (plan->algo != aeth::FFT_ALGO_POW2 || plan->len < 1024 || plan->len > 4096) {
+        // other lengths: the chain on a copy in the plan's temp, then the stand-alone demodulator
+        int rc = aeth::fft_ensure_tmp(plan, n_total); if (rc) return rc;
+        rc = aeth_copy_dev(plan->ctx, plan->tmp_dev, frames, n_total * sizeof(float2)); if (rc) return rc;
+        rc = aeth_fft_mul_ifft(plan, (aeth_cf32 *)plan->tmp_dev, n_total, batch, sig, n_sig, kind_fwd, x_fwd, kind_bwd, x_bwd);
+        if (rc) return rc;
+        return aeth_demod_naive(plan->ctx, (const aeth_cf32 *)plan->tmp_dev, n_total, bps, table, bits_out, nbits_out, compat);
+    }
+    FmiArgs a;
+    a.dbg = 0;
+    a.in = (const cf *)frames; a.out = nullptr; a.hist = nullptr; a.Hf = (const cf *)sig;
+    a.twN = (const cf *)plan->tw_dev; a.twL = (const cf *)plan->tw_lane_dev; a.n = (long long)n_total; a.nblocks = (long long)batch;
+    a.hop = (int)plan->len; a.ov = 0; a.nhist = 0;
+    a.s_fwd = aeth_scale_factor(kind_fwd, plan->len, x_fwd);
+    a.s_bwd = aeth_scale_factor(kind_bwd, plan->len, x_bwd);
+    a.bits = bits_out; a.bps = bps; a.demod_compat = compat;
+    for (int i = 0; i < (bps == 1 ? 2 : 4); i++) { cf t = {tb[i].re, tb[i].im}; a.tab[i] = t; }
     return dispatch_fmi(plan->ctx, plan->len, a);
 }
 

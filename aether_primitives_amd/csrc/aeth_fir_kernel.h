@@ -33,6 +33,10 @@ struct FmiArgs {
     // V_DECIM: only every dec-th output sample is stored, out[i] = y[i * dec] (fir -> sampling::downsample in one pass)
     aeth::FastDiv dec = {1, 0, 0, 0};
     long long n_out = 0;  // samples in `out` = n / dec
+    // V_DEMOD: the chain's output goes through Modulation::demod_naive instead of to memory (hard decisions only)
+    unsigned char *bits = nullptr;    // n * bps bytes, one per bit
+    cf tab[4] = {};                   // BPSK / QPSK symbol table
+    int bps = 0, demod_compat = 0;
 };
 
 // Kernel variants (template parameter VAR, a bit set).  0 is the round-1 kernel.
@@ -44,6 +48,7 @@ enum : int {
     V_PRIO  = 4,    // s_setprio 1 around every LDS exchange (its latency chain is what a block's time is made of)
     V_TOUCH3 = 8,   // with V_TOUCH: three rounds ahead instead of two
     V_DECIM = 512,  // product variant: decimating store (aeth_fir_exec_decim)
+    V_DEMOD = 1024, // product variant: hard demodulation instead of the sample store (aeth_fft_mul_ifft_demod)
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
     V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
     V_CENSUS = 256, // diagnosis only: every wave records HW_ID / XCC_ID in the buffer passed as `chirp`
@@ -156,6 +161,43 @@ __device__ __forceinline__ unsigned touch_window(const FmiArgs &a, long long blk
 
 // CHECK = false: the caller knows that the block exists (no branch around the stores, so that hipcc keeps
 // counting the memory operations in flight across them)
+// Modulation::demod_naive on the block's output samples (modulation.rs:33-56 for [cf32; 4], :133-144 for [cf32; 2]):
+// nearest table symbol by squared distance, first minimum wins; bit bytes to a.bits.  The products are rounded
+// before the sum (opaque asm: this file is built with -ffp-contract=fast, the stand-alone demod kernel without),
+// so the decisions are those of aeth_demod_naive on the stored samples.
+template <class C, bool SCALED>
+__device__ __forceinline__ void demod_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
+{
+    const long long base = blk * a.hop - a.ov;
+    const cf ss = mk(a.s_bwd, a.s_bwd);
+    const int ncand = a.bps * 2;                             // the trait default scans BITS_PER_SYMBOL*2 (:135); QPSK: all four
+#pragma unroll
+    for (int m = 0; m < C::P; m++) {
+        const int e = tid + m * C::T;
+        const long long o = base + e;
+        const cf v = SCALED ? cscale_k(w[m], ss) : w[m];
+        unsigned best = 0;
+        float bd = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (c < ncand) {
+                const float dr = v.x - a.tab[c].x, di = v.y - a.tab[c].y;
+                float p0 = dr * dr, p1 = di * di;
+                asm volatile("" : "+v"(p0), "+v"(p1));
+                const float d = p0 + p1;
+                if (c == 0 || d < bd) { best = (unsigned)c; bd = d; }
+            }
+        }
+        if (e >= a.ov && o < a.n && e < a.frame_n) {
+            if (a.bps == 1) a.bits[o] = (unsigned char)(best & 1u);
+            else {
+                const unsigned hi = a.demod_compat ? (best & 2u) : ((best >> 1) & 1u);          // modulation.rs:54
+                *reinterpret_cast<unsigned short *>(a.bits + 2 * o) = (unsigned short)((best & 1u) | (hi << 8));
+            }
+        }
+    }
+}
+
 template <class C, bool SCALED, bool NT, bool CHECK = true, bool DECIM = false>
 __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
 {
@@ -288,7 +330,8 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         }
         if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f);
         transform_block<C, SCALED, BLU, VAR>(w, tw, H, lds, a, tid);
-        store_block<C, SCALED, NT, false, (VAR & V_DECIM) != 0>(w, a, g0, tid);          // grid <= ngroups: the block exists
+        if constexpr (VAR & V_DEMOD) demod_block<C, SCALED>(w, a, g0, tid);
+        else store_block<C, SCALED, NT, false, (VAR & V_DECIM) != 0>(w, a, g0, tid);     // grid <= ngroups: the block exists
         g0 += gridDim.x;
     } else {
         // software pipeline: the next block's window is in flight while this one is transformed.
@@ -332,7 +375,8 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         if constexpr (VAR & V_NOSTORE) {
 #pragma unroll
             for (int m = 0; m < C::P; m++) asm volatile("" ::"v"(w[m]));
-        } else store_block<C, SCALED, NT, true, (VAR & V_DECIM) != 0>(w, a, blk, tid);
+        } else if constexpr (VAR & V_DEMOD) { if (blk < a.nblocks) demod_block<C, SCALED>(w, a, blk, tid); }
+        else store_block<C, SCALED, NT, true, (VAR & V_DECIM) != 0>(w, a, blk, tid);
     }
     if constexpr (TOUCH) asm volatile("" ::"v"(tprev));
 }

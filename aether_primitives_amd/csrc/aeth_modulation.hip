@@ -5,6 +5,9 @@
 // HBM-bound: modulate reads 1-2 B and writes 8 B per symbol; demod reads 8 B, writes 1-2 B.
 #include "aeth_internal.h"
 
+#define AETH_RNG_FN __host__ __device__ static inline
+#include "aeth_rng.h"
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -139,6 +142,41 @@ __global__ __launch_bounds__(kBlock) void demod_generic_kernel(const float2 *__r
     for (int k = 0; k < bps; k++) bits[i * (size_t)bps + k] = (uint8_t)((best >> k) & 1u);      // :143
 }
 
+// modulate, then Awgn::apply on the fresh symbols (examples/modem.rs:19-26: `let mut tx = qpsk().modulate(&bits);
+// awgn.apply(&mut tx)`) in one pass: the symbol never goes to memory without its noise.  One lane per PAIR of
+// symbols = one Philox call; arithmetic exactly that of modulate_kernel + awgn_apply_kernel (noise.rs:41-42,58).
+template <int BPS, bool NT>
+__global__ __launch_bounds__(kBlock) void modulate_awgn_kernel(const uint8_t *__restrict__ bits, float2 *__restrict__ out,
+                                                               size_t nsym, Table4 t, float scale, uint64_t seed,
+                                                               uint64_t offset, int wide)
+{
+    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t i0 = 2 * p;
+    if (i0 >= nsym) return;
+    const bool two = i0 + 1 < nsym;
+    unsigned idx0, idx1 = 0;
+    if constexpr (BPS == 1) { idx0 = bits[i0] & 1u; if (two) idx1 = bits[i0 + 1] & 1u; }
+    else { idx0 = qpsk_index(bits[2 * i0], bits[2 * i0 + 1]); if (two) idx1 = qpsk_index(bits[2 * i0 + 2], bits[2 * i0 + 3]); }
+    float2 a = pick(t, idx0), b = pick(t, idx1);
+    float n0r, n0i, n1r = 0.f, n1i = 0.f;
+    if ((offset & 1) == 0) {
+        uint32_t w[4];
+        const uint64_t call = (offset + i0) >> 1;
+        aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
+        aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
+    } else {
+        aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
+        if (two) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
+    }
+    a.x = a.x + (n0r * scale) * scale;          // noise.rs:41 then :58
+    a.y = a.y + (n0i * scale) * scale;
+    b.x = b.x + (n1r * scale) * scale;
+    b.y = b.y + (n1i * scale) * scale;
+    if (wide && two) aeth::nt_store<NT>(reinterpret_cast<float4 *>(out + i0), make_float4(a.x, a.y, b.x, b.y));
+    else { out[i0] = a; if (two) out[i0 + 1] = b; }
+}
+
 int fill_table_n(TableN &t, int bps, const aeth_cf32 *host)
 {
     AETH_REQUIRE(bps >= 3 && bps <= 8, AETH_E_UNSUPPORTED, "bits_per_symbol %d: 1 .. 8 supported", bps);
@@ -204,6 +242,36 @@ int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, con
     else if (vec)        AETH_MOD(2, true, gv);
     else                 AETH_MOD(2, false, gs);
 #undef AETH_MOD
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+int aeth_modulate_awgn(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, const aeth_cf32 *table, aeth_cf32 *out,
+                       size_t n_out, float power, uint64_t seed, uint64_t offset)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    Table4 t;
+    int rc = fill_table(t, bps, table); if (rc) return rc;          // BPSK / QPSK (the reference's modem example)
+    AETH_REQUIRE(nbits % (size_t)bps == 0, AETH_E_LEN, "bit count %zu is not a multiple of BITS_PER_SYMBOL %d", nbits, bps);
+    AETH_REQUIRE(n_out == nbits / (size_t)bps, AETH_E_LEN, "output holds %zu symbols, input gives %zu", n_out, nbits / (size_t)bps);
+    AETH_REQUIRE(power >= 0.0f, AETH_E_ARG, "noise power must be >= 0");
+    if (n_out == 0) return AETH_OK;
+    AETH_REQUIRE(bits && out, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(out), AETH_E_ALIGN, "pointer alignment");
+    aeth::DeviceGuard dev_guard(ctx->device);
+    const float scale = sqrtf(power);                               // noise.rs:35
+    const size_t pairs = (n_out + 1) / 2;
+    const bool nt = aeth::streams_past_cache(n_out * sizeof(float2));
+    const int wide = aeth::aligned16(out) ? 1 : 0;
+#define AETH_MA(B)                                                                                                              \
+    do {                                                                                                                        \
+        if (nt) hipLaunchKernelGGL((modulate_awgn_kernel<B, true>), dim3(grid_for(pairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx), \
+                                   bits, (float2 *)out, n_out, t, scale, seed, offset, wide);                                  \
+        else hipLaunchKernelGGL((modulate_awgn_kernel<B, false>), dim3(grid_for(pairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx),   \
+                                bits, (float2 *)out, n_out, t, scale, seed, offset, wide);                                     \
+    } while (0)
+    if (bps == 1) AETH_MA(1); else AETH_MA(2);
+#undef AETH_MA
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

@@ -60,6 +60,31 @@ class _Modulation:
                                       self.table.ctypes.data_as(C.c_void_p), out._p(), out.n))
         return out
 
+    def modulate_awgn(self, bits, awgn, out=None):              # examples/modem.rs:19-26: modulate, then awgn.apply, one pass
+        if not isinstance(bits, DeviceBits):
+            bits = DeviceBits(self.ctx, len(bits), bits)
+        if out is None:
+            out = DeviceVec(self.ctx, bits.n // self.BITS_PER_SYMBOL)
+        check(self._lib.aeth_modulate_awgn(self.ctx.h, C.c_void_p(bits.ptr), bits.n, self.BITS_PER_SYMBOL,
+                                           self.table.ctypes.data_as(C.c_void_p), out._p(), out.n, awgn.power, awgn.seed,
+                                           awgn.offset))
+        awgn.offset += out.n
+        return out
+
+    def correlate_demod(self, fft, frames, sig, s_fwd=None, s_bwd=None, compat=True, out=None):
+        """frames.vec_rfft(fft).vec_mul(sig).vec_rifft(fft) per frame, then demod_naive: only the bits are written
+        (examples/modem.rs:28-31 behind the correlator of benches.rs:410-416); `frames` stays as it was."""
+        from .fft import Scale
+        s_fwd = s_fwd or Scale.NONE; s_bwd = s_bwd or Scale.NONE
+        if out is None:
+            out = DeviceBits(self.ctx, frames.n * self.BITS_PER_SYMBOL)
+        n = fft.len()
+        check(self._lib.aeth_fft_mul_ifft_demod(fft.h, frames._p(), frames.n, frames.n // n if n else 0, sig._p(), sig.n,
+                                                s_fwd.kind, s_fwd.x, s_bwd.kind, s_bwd.x, self.BITS_PER_SYMBOL,
+                                                self.table.ctypes.data_as(C.c_void_p), C.c_void_p(out.ptr), out.n,
+                                                1 if compat else 0))
+        return out
+
     def demod_naive(self, symbols, compat=True, out=None):      # modulation.rs:33-56 / :133-144
         if out is None:
             out = DeviceBits(self.ctx, symbols.n * self.BITS_PER_SYMBOL)

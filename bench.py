@@ -256,11 +256,17 @@ def side_workload(args):
             rng = np.random.default_rng(815 + c)
             chans.append((modulation.DeviceBits(ctx, 2 * n, rng.integers(0, 2, 2 * n, dtype=np.uint8)),
                           noise.new(ctx, 0.01, 815 + c), ctx.empty(n), modulation.DeviceBits(ctx, 2 * n)))
-        def step(i):
-            for bits, awgn, txb, rxb in chans:
-                tx = q.modulate(bits, out=txb); awgn.apply(tx); f.mul_chain(tx, sig); q.demod_naive(tx, out=rxb)
+        if args.c4_unfused:
+            def step(i):                                        # four launches per channel: 52 B of traffic per sample
+                for bits, awgn, txb, rxb in chans:
+                    tx = q.modulate(bits, out=txb); awgn.apply(tx); f.mul_chain(tx, sig); q.demod_naive(tx, out=rxb)
+        else:
+            def step(i):                                        # two launches: modulate+AWGN, correlate+demod: 20 B per sample
+                for bits, awgn, txb, rxb in chans:
+                    tx = q.modulate_awgn(bits, awgn, out=txb); q.correlate_demod(f, tx, sig, out=rxb)
         job_samples = n * n_channels
-        name = "C4: 8 channels x (QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod), 4096 frames each"
+        name = "C4: 8 channels x (QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod), 4096 frames each" + (
+            " (four calls)" if args.c4_unfused else " (modulate_awgn + mul_ifft_demod)")
         bytes_ = 52 * n * len(mine)
         shard = f"channel_of: rank 0 runs channels {mine}"
     ranks.barrier(ctx)
@@ -309,6 +315,7 @@ def main():
                           "the previous one to drain; this is also the mode to profile per-kernel durations in")
     ap_.add_argument("--no-single-queue-leg", action="store_true",
                      help="skip the extra leg that repeats the timed steps on one queue (per-launch kernel time)")
+    ap_.add_argument("--c4-unfused", action="store_true", help="--workload c4 as four calls per channel (modulate, apply, mul_chain, demod)")
     ap_.add_argument("--c5-unfused", action="store_true", help="--workload c5 as two calls (fft, then interpolate)")
     ap_.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],
                      help="c3 (default) = the headline config; the others are BASELINE configs 2, 4, 5 for the record")

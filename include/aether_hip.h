@@ -187,6 +187,15 @@ AETH_API int aeth_fft_exec_tmp(aeth_fft *plan, const aeth_cf32 *in, size_t n_in,
 AETH_API int aeth_fft_mul_ifft(aeth_fft *plan, aeth_cf32 *frames_dev, size_t n_total, size_t batch,
                                const aeth_cf32 *sig_dev, size_t n_sig,
                                int scale_kind_fwd, float x_fwd, int scale_kind_bwd, float x_bwd);
+/* The same chain followed by Modulation::demod_naive on its output (examples/modem.rs:28-31; BASELINE config 4's
+ * receive side): only the bit bytes are written, `frames` is not modified.  BPSK / QPSK (table_host NULL = the generic
+ * tables, `compat` as in aeth_demod_naive).  For plan lengths 1024 .. 4096 the decisions are taken in the chain's
+ * registers; other lengths run the two steps through the plan's temp.  Same bits as aeth_fft_mul_ifft +
+ * aeth_demod_naive. */
+AETH_API int aeth_fft_mul_ifft_demod(aeth_fft *plan, const aeth_cf32 *frames_dev, size_t n_total, size_t batch,
+                                     const aeth_cf32 *sig_dev, size_t n_sig, int scale_kind_fwd, float x_fwd,
+                                     int scale_kind_bwd, float x_bwd, int bits_per_symbol,
+                                     const aeth_cf32 *table_host, uint8_t *bits_out_dev, size_t nbits_out, int compat);
 
 /* ---- FIR (src/fir.rs:3-22 holds taps + scratch but no filter method) ------- */
 /* y[n] = sum_{k<ntaps} taps[k] * x[n-k] by overlap-save built from the
@@ -261,6 +270,12 @@ AETH_API int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src,
  * nbits must be a multiple of bits_per_symbol (AETH_E_LEN) and n_out == nbits / bits_per_symbol. */
 AETH_API int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits_dev, size_t nbits, int bits_per_symbol,
                            const aeth_cf32 *table_host, aeth_cf32 *out_dev, size_t n_out);
+/* modulate followed by Awgn::apply on the fresh symbols (examples/modem.rs:19-26) in one pass over memory:
+ * out[s] = table[index] + (z * scale) * scale with z = position offset + s of stream `seed` (see aeth_awgn_apply).
+ * BPSK / QPSK tables; bit-identical to aeth_modulate + aeth_awgn_apply. */
+AETH_API int aeth_modulate_awgn(aeth_ctx *ctx, const uint8_t *bits_dev, size_t nbits, int bits_per_symbol,
+                                const aeth_cf32 *table_host, aeth_cf32 *out_dev, size_t n_out, float power,
+                                uint64_t seed, uint64_t offset);
 /* Modulation::demod_naive: nearest table symbol by squared distance, the FIRST minimum wins
  * (min_by keeps the first of equals).  compat != 0 reproduces the QPSK specialisation's
  * output exactly (:33-56): it pushes `idx & 1` and `idx & 1u8 << 1` == idx & 2, i.e. the

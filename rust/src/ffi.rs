@@ -88,6 +88,9 @@ extern "C" {
                                   scale_kind: c_int, x: c_float, view: *mut *const cf32) -> c_int;
     pub fn aeth_fft_mul_ifft(plan: *mut aeth_fft, frames: *mut cf32, n_total: usize, batch: usize,
                              sig: *const cf32, n_sig: usize, kf: c_int, xf: c_float, kb: c_int, xb: c_float) -> c_int;
+    pub fn aeth_fft_mul_ifft_demod(plan: *mut aeth_fft, frames: *const cf32, n_total: usize, batch: usize, sig: *const cf32, n_sig: usize,
+                                   kind_fwd: c_int, x_fwd: c_float, kind_bwd: c_int, x_bwd: c_float, bps: c_int,
+                                   table: *const cf32, bits_out: *mut u8, nbits_out: usize, compat: c_int) -> c_int;
 
     pub fn aeth_fir_create(ctx: *mut aeth_ctx, taps: *const cf32, ntaps: usize, fft_len: usize,
                            out: *mut *mut aeth_fir) -> c_int;
@@ -117,6 +120,8 @@ extern "C" {
                                  n_between: usize, compat_im: c_int, n_written: *mut usize) -> c_int;
     pub fn aeth_modulate(ctx: *mut aeth_ctx, bits: *const u8, nbits: usize, bits_per_symbol: c_int,
                          table: *const cf32, out: *mut cf32, n_out: usize) -> c_int;
+    pub fn aeth_modulate_awgn(ctx: *mut aeth_ctx, bits: *const u8, nbits: usize, bps: c_int, table: *const cf32, out: *mut cf32,
+                              n_out: usize, power: c_float, seed: u64, offset: u64) -> c_int;
     pub fn aeth_demod_naive(ctx: *mut aeth_ctx, sym: *const cf32, nsym: usize, bits_per_symbol: c_int,
                             table: *const cf32, bits_out: *mut u8, nbits_out: usize, compat: c_int) -> c_int;
     pub fn aeth_awgn_apply(ctx: *mut aeth_ctx, signal: *mut cf32, n: usize, power: c_float, seed: u64, offset: u64) -> c_int;

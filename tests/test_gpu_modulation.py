@@ -166,6 +166,48 @@ def test_awgn_distribution_ks_and_tails(ctx):
     assert abs(np.corrcoef(z.real[: 1 << 22], z.imag[: 1 << 22])[0, 1]) < 5 / np.sqrt(1 << 22)
 
 
+@pytest.mark.parametrize("bps,nsym,offset", [(2, 1, 0), (2, 7, 3), (2, 4096, 0), (1, 100001, 5), (2, 1 << 20, 1 << 33), (1, 2, 1)])
+def test_modulate_awgn_fused_bit_exact(ctx, oracle, bps, nsym, offset):
+    """modulate + Awgn::apply in one pass (examples/modem.rs:19-26) == the two calls, bit for bit; the stream
+    position advances like the generator's state"""
+    rng = np.random.default_rng(nsym)
+    bits = rng.integers(0, 2, nsym * bps, dtype=np.uint8)
+    mod = modulation.qpsk(ctx) if bps == 2 else modulation.bpsk(ctx)
+    for power in (1.0, 0.01):
+        g1 = noise.new(ctx, power, 815); g1.offset = offset
+        two = mod.modulate(bits); g1.apply(two)
+        g2 = noise.new(ctx, power, 815); g2.offset = offset
+        buf = ctx.vec(np.full(nsym + 2, 3 + 3j, np.complex64))
+        mod.modulate_awgn(bits, g2, out=buf.slice(1, nsym + 1))        # 8- but not 16-byte aligned destination
+        h = buf.to_host()
+        assert bits_equal(h[1:nsym + 1], two.to_host()) and h[0] == 3 + 3j and h[-1] == 3 + 3j
+        assert g2.offset == g1.offset == offset + nsym
+        assert bits_equal(mod.modulate_awgn(bits, noise.new(ctx, power, 815)).to_host(),
+                          oracle.awgn_apply(oracle.modulate(bits, bps), power, 815, 0))
+
+
+@pytest.mark.parametrize("n,frames,bps", [(2048, 64, 2), (1024, 33, 2), (4096, 5, 1), (2048, 3, 1), (256, 40, 2), (100, 12, 2)])
+def test_correlate_then_demod_in_one_call(ctx, oracle, n, frames, bps):
+    """rfft * sig -> rifft -> demod_naive with only the bits written: same bits as the two calls (both compat modes),
+    input frames untouched; lengths outside 1024..4096 take the two-step path"""
+    rng = np.random.default_rng(n + frames)
+    bits = rng.integers(0, 2, bps * n * frames, dtype=np.uint8)
+    mod = modulation.qpsk(ctx) if bps == 2 else modulation.bpsk(ctx)
+    tx = mod.modulate_awgn(bits, noise.new(ctx, 0.3, 815))             # strong noise: decisions near the boundaries too
+    x = tx.to_host()
+    f = HipFft(ctx, n, max_batch=frames)
+    sig = ctx.vec(rand_c64(9, n))
+    ref = ctx.vec(x); f.mul_chain(ref, sig)
+    for compat in (True, False):
+        want = mod.demod_naive(ref, compat=compat).to_host()
+        got = mod.correlate_demod(f, tx, sig, compat=compat).to_host()
+        assert (got == want).all()
+    assert bits_equal(tx.to_host(), x)
+    # scaled variant (Scale::SN both ways)
+    ref2 = ctx.vec(x); f.mul_chain(ref2, sig, Scale.SN, Scale.SN)
+    assert (mod.correlate_demod(f, tx, sig, Scale.SN, Scale.SN).to_host() == mod.demod_naive(ref2).to_host()).all()
+
+
 def test_c4_chain(ctx, oracle):
     """QPSK mod -> AWGN (power 0.01, examples/modem.rs:25) -> per 2048-frame rfft * conj-reference
     -> rifft -> hard demod.  Correlating against a unit impulse reference leaves the frame
