@@ -92,4 +92,19 @@ report("qpsk modulate 2^25 symbols", 10 * nsym, timeit(lambda i: q.modulate(bits
 report("qpsk demod_naive 2^25 symbols", 10 * nsym, timeit(lambda i: q.demod_naive(A[i % NB], out=outb)), nsym)
 g = noise.new(ctx, 0.01, 815)
 report("awgn apply 2^25 samples", 16 * nsym, timeit(lambda i: g.apply(A[i % NB])), nsym)
+# round 2: fused / new entry points
+report("qpsk modulate_awgn (fused) 2^25 symbols", 10 * nsym, timeit(lambda i: q.modulate_awgn(bits, g, out=A[i % NB])), nsym)
+report("correlate + demod (fused) N=2048 batch=16384", 10 * n, timeit(lambda i: q.correlate_demod(f, A[i % NB], sig, out=outb)), n)
+report("awgn fill 2^25 samples", 8 * nsym, timeit(lambda i: g.fill(A[i % NB])), nsym)
+sig100 = ctx.vec(host[:100]); m100 = (n // 100) * 100
+report("vec_mul_frames N=100 (one launch, 335544 frames)", 16 * m100, timeit(lambda i: A[i % NB].slice(0, m100).vec_mul_frames(sig100)), m100)
+fir = ap.Fir(ctx, host[:64] * 0.1, 2048)
+half = n // 2
+for dec in (4, 16):
+    dd = ctx.empty(half // dec)
+    report(f"fir + decimating store dec={dec} (16 Mi in)", 8 * half + 8 * half // dec, timeit(lambda i: fir.filter_decim(A[i % NB].slice(0, half), dec, out=dd)), half)
+report("fft + mirror epilogue N=2048", 16 * n, timeit(lambda i: f.rfft_mirror(A[i % NB], Scale.SN)), n)
+for N in (17, 61, 323, 1003, 2006):
+    fp = ap.HipFft(ctx, N); m = (n // N) * N
+    report(f"fft ifwd N={N} batch={m // N} ({fp.algorithm})", 16 * m, timeit(lambda i: fp.ifwd(A[i % NB].slice(0, m), Scale.SN)), m)
 json.dump(rows, open("gpurun_out/kernel_survey.json", "w"), indent=1)
