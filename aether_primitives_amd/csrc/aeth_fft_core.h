@@ -489,6 +489,11 @@ struct Cfg {
 };
 
 __device__ __forceinline__ int lidx(int e) { return e + (e >> 4); }
+// XOR swizzle of the exchange image (tuning, XP bit 3): element e sits in slot e ^ ((e >> 4) & 15) -- a permutation
+// inside every aligned group of 16 elements.  Like the pad it spreads the stride-16 writes of the first exchange over
+// 16 slots, and unlike the pad it keeps 32 consecutive elements inside one 256-byte bank row, so the contiguous
+// reads lose their two-way conflict.
+template <int XP> __device__ __forceinline__ int pidx(int e) { return (XP & 8) ? (e ^ ((e >> 4) & 15)) : lidx(e); }
 
 // twN: master table exp(-2 pi i k / N), k in [0, N)
 template <class C, int PASS>
@@ -608,7 +613,7 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
             const int k = i % p;
             const int j = (i - k) * R + k;
 #pragma unroll
-            for (int r = 0; r < R; r++) img[lidx(j + r * p)] = u[r];
+            for (int r = 0; r < R; r++) img[pidx<XP>(j + r * p)] = u[r];
         }
     }
     if constexpr (!last && !NOLDS) {
@@ -616,7 +621,7 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
         if constexpr (XP & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         else __syncthreads();
 #pragma unroll
-        for (int m = 0; m < C::P; m++) w[m] = img[lidx(tid + m * C::T)];
+        for (int m = 0; m < C::P; m++) w[m] = img[pidx<XP>(tid + m * C::T)];
         if constexpr (XP & 1) __builtin_amdgcn_s_setprio(0);
     }
 }

@@ -59,7 +59,9 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     }
     // one-frame workgroups run their LDS exchanges at raised wave priority (V_PRIO: -0.3 ... -0.5 us per 16 Mi-sample
     // launch in tools/fir_lab, A/B in one process); the other variants of aeth_fir_kernel.h measured null or negative
-    constexpr int VAR = (C::F == 1) ? V_PRIO : 0;
+    // ... and N = 2048 (the configuration it was measured on) keeps its exchange image XOR-swizzled instead of padded:
+    // no two-way conflict on the contiguous reads, transform-only time 39.8 -> 34.8 us, launch 54.8 -> 53.4 us
+    constexpr int VAR = (C::F == 1) ? (V_PRIO | (C::N == 2048 ? V_XOR : 0)) : 0;
     if constexpr (C::F == 1) {
         if (b.bits) {                                       // hard demodulation instead of the sample store
             if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR | V_DEMOD>), dim3(grid), dim3(C::WG), 0, stream, b);

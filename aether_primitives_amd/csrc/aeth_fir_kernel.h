@@ -48,6 +48,7 @@ enum : int {
     V_PRIO  = 4,    // s_setprio 1 around every LDS exchange (its latency chain is what a block's time is made of)
     V_TOUCH3 = 8,   // with V_TOUCH: three rounds ahead instead of two
     V_DECIM = 512,  // product variant: decimating store (aeth_fir_exec_decim)
+    V_XOR = 2048,   // XOR-swizzled LDS exchange image instead of the padded one (see aeth_fft_core.h: pidx)
     V_DEMOD = 1024, // product variant: hard demodulation instead of the sample store (aeth_fft_mul_ifft_demod)
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
     V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
@@ -252,7 +253,7 @@ template <class C, bool SCALED, bool BLU, int VAR>
 __device__ __forceinline__ void transform_block(cf (&w)[C::P], const cf (&tw)[C::TW], const cf (&H)[C::P],
                                                 cf *__restrict__ lds, const FmiArgs &a, int tid)
 {
-    constexpr int XP = ((VAR & V_PRIO) ? 1 : 0) | ((VAR & V_NOBAR) ? 2 : 0) | ((VAR & V_NOLDS) ? 4 : 0);
+    constexpr int XP = ((VAR & V_PRIO) ? 1 : 0) | ((VAR & V_NOBAR) ? 2 : 0) | ((VAR & V_NOLDS) ? 4 : 0) | ((VAR & V_XOR) ? 8 : 0);
     if constexpr (BLU) {
         // x[n] (conjugated for the other exponent sign) * chirp[n]; chirp is 0 beyond the frame (descriptor range)
         auto cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.chirp), 0, a.frame_n * 8, 0x00020000);
