@@ -32,7 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #ifndef AETH_LDS_DB_LIMIT
-#define AETH_LDS_DB_LIMIT (24 * 1024)   /* two exchange images per workgroup up to this many bytes (more would cost occupancy) */
+#define AETH_LDS_DB_LIMIT (36 * 1024)   /* two exchange images per workgroup up to this many bytes (N <= 2048: one barrier per exchange; more would cost occupancy) */
 #endif
 
 namespace aeth {
