@@ -48,6 +48,7 @@ enum : int {
     V_PRIO  = 4,    // s_setprio 1 around every LDS exchange (its latency chain is what a block's time is made of)
     V_TOUCH3 = 8,   // with V_TOUCH: three rounds ahead instead of two
     V_DECIM = 512,  // product variant: decimating store (aeth_fir_exec_decim)
+    V_UNROLL2 = 4096, // the block loop unrolled by two with the roles of the two window register sets swapped (no copy)
     V_XOR = 2048,   // XOR-swizzled LDS exchange image instead of the padded one (see aeth_fft_core.h: pidx)
     V_DEMOD = 1024, // product variant: hard demodulation instead of the sample store (aeth_fft_mul_ifft_demod)
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
@@ -227,6 +228,7 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
     } else if constexpr (C::F == 1) {
         long long left = a.n - base;
         int bytes = (int)(left < a.frame_n ? left : a.frame_n) * 8;   // stores past the end (of the stream, of the frame) are dropped by the range check
+        if constexpr (!CHECK) { if (blk >= a.nblocks) bytes = 0; }    // a block past the end: every store dropped, no branch
         auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out + base, 0, bytes, 0x00020000);
         const cf ss = mk(a.s_bwd, a.s_bwd);
         // no branch around the stores either: window elements in front of the valid part
@@ -347,6 +349,23 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         // through each block -- forcing the prefetched window AND the previous block's stores to
         // complete there instead of riding under the whole block.
         __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only
+    }
+    if constexpr ((VAR & V_UNROLL2) && C::F == 1 && !BLU && !(VAR & (V_DEMOD | V_DECIM | V_TOUCH | V_NOLOAD | V_NOSTORE))) {
+        // two blocks per trip: window registers A (= nx) and B swap roles, so no block starts with a 32-register copy.
+        // Everything stays branch-free (blocks past the end load and store through zero-length descriptors).
+        cf wb[C::P];
+        auto one = [&](cf (&cur)[C::P], cf (&nxt)[C::P], long long g) {
+            if (tid < a.ov - a.nhist) cur[0] = mk(0.f, 0.f);
+            load_window_srd<C, NT>(nxt, a, g + gridDim.x, tid);
+            transform_block<C, SCALED, BLU, VAR>(cur, tw, H, lds, a, tid);
+            store_block<C, SCALED, NT, false, false>(cur, a, g, tid);
+        };
+#pragma unroll 1
+        for (long long g = g0; g < ngroups; g += 2 * (long long)gridDim.x) {
+            one(nx, wb, g);
+            one(wb, nx, g + gridDim.x);
+        }
+        return;
     }
 #pragma unroll 1
     for (long long g = g0; g < ngroups; g += gridDim.x) {
