@@ -246,6 +246,11 @@ public:
         y.resize(x.size());
         check(aeth_fir_exec_host(h_, nullptr, raw(x.data()), x.size(), raw(y.data())));
     }
+    // the filter followed by sampling::downsample (sampling.rs:28-42) in one pass: y[i] = fir(x)[i * (x.len / y.len)]
+    void filter_decim(const DeviceVec &x, DeviceVec &y, const DeviceVec *hist = nullptr)
+    {
+        check(aeth_fir_exec_decim(h_, hist ? hist->ptr() : nullptr, x.ptr(), x.len(), y.ptr(), y.len()));
+    }
 
 private:
     aeth_fir *h_ = nullptr;

@@ -121,6 +121,31 @@ int main()
         for (int k = 64; k < 5000; k++) if (std::abs(y[k]) > 1e-6f) throw Panic(0, "tail");
     });
 
+    // overlap lane + decimating store: consecutive independent launches on two queues give the bits of the plain run
+    RUN("fir on the overlap lane, and with a decimating store", {
+        std::vector<cf32> taps(64); for (int k = 0; k < 64; k++) taps[k] = cf32(1.0f / (k + 1), 0.01f * k);
+        const size_t n = 1984 * 40;
+        std::vector<cf32> a(n), b(n);
+        for (size_t i = 0; i < n; i++) { a[i] = cf32(std::sin(0.01f * i), std::cos(0.013f * i)); b[i] = cf32(std::cos(0.02f * i), 0.5f); }
+        Fir fir(ctx, taps, 2048);
+        DeviceVec da(ctx, a), db(ctx, b), ya(ctx, n), yb(ctx, n), ra(ctx, n), rb(ctx, n);
+        fir.filter(da, ra); fir.filter(db, rb);
+        const std::vector<cf32> wa = ra.to_host(), wb = rb.to_host();
+        ctx.set_overlap(true);
+        for (int rep = 0; rep < 4; rep++) { fir.filter(da, ya); fir.filter(db, yb); }
+        const std::vector<cf32> ga = ya.to_host(), gb = yb.to_host();
+        ctx.set_overlap(false);
+        if (std::memcmp(ga.data(), wa.data(), n * sizeof(cf32)) || std::memcmp(gb.data(), wb.data(), n * sizeof(cf32))) throw Panic(0, "overlap lane changed the output");
+        DeviceVec yd(ctx, n / 8);
+        fir.filter_decim(da, yd);
+        const std::vector<cf32> gd = yd.to_host();
+        for (size_t i = 0; i < n / 8; i++) if (std::memcmp(&gd[i], &wa[8 * i], sizeof(cf32))) throw Panic(0, "decimated output");
+    });
+    EXPECT_PANIC("fir decimation 7000 -> 2333", "Only even decimations are supported", {
+        std::vector<cf32> taps(8, cf32(0.125f, 0)); Fir fir(ctx, taps, 2048);
+        DeviceVec x(ctx, 7000), y(ctx, 2333); fir.filter_decim(x, y);
+    });
+
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "PASSED", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
 }
