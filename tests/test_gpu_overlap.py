@@ -96,6 +96,54 @@ def test_other_ops_join_the_lane(octx, oracle):
     assert e0.elapsed_ms(e1) > 8 * (n / 500e9) * 1e3 * 0.5      # at least half of what 8 launches need at 500 GS/s
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_call_sequences_match_a_plain_context(seed, oracle):
+    """Random programs over a pool of buffers -- filters between random pairs (sometimes chained, sometimes clobbering
+    an earlier input or output, sometimes on overlapping slices), element-wise ops, downloads, syncs -- give the same
+    bits on a context with the overlap lane as on a plain one."""
+    rng = np.random.default_rng(seed)
+    n, nbuf = 1 << 18, 6
+    taps = oracle.synth_lowpass_taps(64, 0.25)
+    init = [rand_c64(1000 * seed + i, n) for i in range(nbuf)]
+    prog = []
+    for _ in range(120):
+        k = rng.integers(10)
+        if k < 6:
+            i, j = rng.choice(nbuf, 2, replace=False)
+            if rng.integers(4) == 0:                     # overlapping views of one buffer as input of one call, output of the next
+                lo = int(rng.integers(0, n // 2)); prog.append(("fir_slice", int(i), int(j), lo, lo + n // 2))
+            else:
+                prog.append(("fir", int(i), int(j)))
+        elif k < 8:
+            i, j = rng.choice(nbuf, 2, replace=False); prog.append(("add", int(i), int(j)))
+        elif k == 8:
+            prog.append(("scale", int(rng.integers(nbuf)), float(rng.uniform(0.5, 1.5))))
+        else:
+            prog.append(("peek", int(rng.integers(nbuf))))
+
+    def run(c):
+        f = Fir(c, taps, 2048)
+        b = [c.vec(x) for x in init]
+        peeks = []
+        for op in prog:
+            if op[0] == "fir": f.filter(b[op[1]], out=b[op[2]])
+            elif op[0] == "fir_slice": f.filter(b[op[1]].slice(op[3], op[4]), out=b[op[2]].slice(op[3], op[4]))
+            elif op[0] == "add": b[op[1]].vec_add(b[op[2]])
+            elif op[0] == "scale": b[op[1]].vec_scale(op[2])
+            else: peeks.append(b[op[1]].slice(0, 64).to_host())
+        return [v.to_host() for v in b], peeks
+
+    plain = ap.Context(0)
+    lane = ap.Context(0); lane.set_overlap(True)
+    want, wp = run(plain)
+    got, gp = run(lane)
+    for a, b in zip(want, got):
+        assert bits_equal(a, b)
+    for a, b in zip(wp, gp):
+        assert bits_equal(a, b)
+    plain.close(); lane.close()
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     from oracle import pyoracle as orc
