@@ -315,12 +315,45 @@ __device__ __forceinline__ void bfly7(cf (&u)[7], const cf *__restrict__ twN, in
     }
 }
 
+// odd prime R in registers, the same symmetric-pair form: (R-1)^2/2 real multiply-adds on packed pairs instead
+// of the (R-1)^2 complex ones of the O(R^2) pass, roots W_R^1..W_R^{(R-1)/2} read once (wave-uniform addresses)
+template <int R>
+__device__ __forceinline__ void bfly_sym(cf (&u)[R], const cf *__restrict__ twN, int n)
+{
+    constexpr int H = (R - 1) / 2;
+    cf s[H], d[H], w[H];
+    const int step = n / R;
+#pragma unroll
+    for (int m = 0; m < H; m++) { s[m] = cadd(u[m + 1], u[R - 1 - m]); d[m] = csub(u[m + 1], u[R - 1 - m]); w[m] = twN[(m + 1) * step]; }
+    const cf x0 = u[0];
+    cf sum = x0;
+#pragma unroll
+    for (int m = 0; m < H; m++) sum = cadd(sum, s[m]);
+    u[0] = sum;
+#pragma unroll
+    for (int k = 1; k <= H; k++) {
+        cf re = x0, im = mk(0.f, 0.f);
+#pragma unroll
+        for (int m = 1; m <= H; m++) {
+            const int idx = (k * m) % R;                    // W_R^idx = (cos, -sin); W_R^{R-idx} is its conjugate
+            const cf wa = idx > H ? w[R - idx - 1] : w[idx - 1];
+            const float sn = idx > H ? -wa.y : wa.y;
+            re.x += wa.x * s[m - 1].x; re.y += wa.x * s[m - 1].y;
+            im.x += sn * d[m - 1].x; im.y += sn * d[m - 1].y;
+        }
+        const cf jim = mk(-im.y, im.x);
+        u[k] = cadd(re, jim);
+        u[R - k] = csub(re, jim);
+    }
+}
+
 template <int R>
 __device__ __forceinline__ void mixed_bfly(cf (&u)[R], const cf *__restrict__ twN, int n)
 {
     if constexpr (R == 3) bfly3(u[0], u[1], u[2]);
     else if constexpr (R == 5) bfly5(u[0], u[1], u[2], u[3], u[4]);
     else if constexpr (R == 7) bfly7(u, twN, n);
+    else if constexpr (R == 11 || R == 13 || R == 17 || R == 19 || R == 23) bfly_sym<R>(u, twN, n);
     else Bfly<R, -1>::run(u);
 }
 
@@ -419,7 +452,9 @@ __device__ __forceinline__ void mixed_pass_prime(const MixedPass &ps, int n, int
 }
 
 // PTS = 0: two LDS images per frame (ping-pong); PTS > 0: one image, a lane holds up to PTS points across the barrier
-template <bool SWAP, int PTS>
+// BIGR: the register butterflies for 11 .. 23 are compiled in (144-170 VGPRs against 83-91 without them, so plans
+// that have no such factor keep the lean build and its five waves per SIMD)
+template <bool SWAP, int PTS, bool BIGR>
 __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *out, const cf *__restrict__ twN,
                                                               const cf *twP, MixedDesc d, size_t batch,
                                                               float scale, int tpf, int tw_lds)
@@ -474,7 +509,18 @@ __global__ __launch_bounds__(kMixedWG) void fft_mixed_kernel(const cf *in, cf *o
             case 5: AETH_PASS(5); break;
             case 7: AETH_PASS(7); break;
             case 8: AETH_PASS(8); break;
-            default: mixed_pass_prime<SWAP>(ps, n, lane, tpf, tg, active, gout, X, Y, twP, twN, scale); break;
+            default:
+                if constexpr (BIGR) {
+                    switch (ps.R) {
+                    case 11: AETH_PASS(11); break;
+                    case 13: AETH_PASS(13); break;
+                    case 17: AETH_PASS(17); break;
+                    case 19: AETH_PASS(19); break;
+                    case 23: AETH_PASS(23); break;
+                    default: mixed_pass_prime<SWAP>(ps, n, lane, tpf, tg, active, gout, X, Y, twP, twN, scale); break;
+                    }
+                } else mixed_pass_prime<SWAP>(ps, n, lane, tpf, tg, active, gout, X, Y, twP, twN, scale);
+                break;
             }
 #undef AETH_PASS
             __syncthreads();
@@ -499,7 +545,11 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
         pp *= ps.R;
     }
     auto small_radix = [](int r) { return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8; };
-    d.stage = (d.nfac == 1 || (d.nfac > 0 && !small_radix(d.pass[0].R))) ? 1 : 0;
+    auto big_radix = [](int r) { return r == 11 || r == 13 || r == 17 || r == 19 || r == 23; };
+    bool bigr = false;
+    for (int i = 0; i < d.nfac; i++) bigr = bigr || big_radix(d.pass[i].R);
+    bigr = bigr && aeth::tuning_int("AETH_MIXED_BIGR", 1) != 0;
+    d.stage = (d.nfac == 1 || (d.nfac > 0 && !small_radix(d.pass[0].R) && !(bigr && big_radix(d.pass[0].R)))) ? 1 : 0;
     // Lanes per frame.  These kernels are latency-bound (a chain of short passes with a barrier each), so
     // what counts is how many frames a CU has in flight, and the number of workgroups per CU is capped by
     // registers (~6).  So: as many frames per workgroup as ~36 KiB of LDS images allow (4-5 workgroups
@@ -538,7 +588,11 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
         shmem += (size_t)off * sizeof(cf);
     }
 #define AETH_MIXED_LAUNCH(SW, IP)                                                                                        \
-    hipLaunchKernelGGL((fft_mixed_kernel<SW, IP>), dim3(grid), dim3(kMixedWG), shmem, aeth::ctx_stream(ctx), (const cf *)in,       \
+    if (bigr && IP == 0)                                                                                                 \
+        hipLaunchKernelGGL((fft_mixed_kernel<SW, 0, true>), dim3(grid), dim3(kMixedWG), shmem, aeth::ctx_stream(ctx), (const cf *)in, \
+                           (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds); \
+    else                                                                                                                 \
+    hipLaunchKernelGGL((fft_mixed_kernel<SW, IP, false>), dim3(grid), dim3(kMixedWG), shmem, aeth::ctx_stream(ctx), (const cf *)in,       \
                        (cf *)out, (const cf *)plan->tw_dev, (const cf *)plan->tw_pass_dev, d, batch, scale, tpf, tw_lds)
 #define AETH_MIXED_SIGN(IP) do { if (sign > 0) AETH_MIXED_LAUNCH(true, IP); else AETH_MIXED_LAUNCH(false, IP); } while (0)
     switch (pts) {
@@ -699,7 +753,7 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
     } else if (aeth::fft_ragged_supported(len) && !aeth::tuning_int("AETH_FFT_NORAGGED", 0)) {
         p->algo = aeth::FFT_ALGO_RAGGED;
         p->algo_name = "stockham_mixed_ragged";
-    } else if (2 * len - 1 <= 4096 && largest_prime_factor(len) >= 17 && aeth::tuning_int("AETH_FFT_PRIME_BLU", 1)) {
+    } else if (2 * len - 1 <= 4096 && largest_prime_factor(len) >= (size_t)aeth::tuning_int("AETH_FFT_PRIME_BLU_MIN", 17) && aeth::tuning_int("AETH_FFT_PRIME_BLU", 1)) {
         // a prime factor from 17 up and a chirp-z convolution that fits the one-launch kernel (M <= 4096): 1.4-2.6 TB/s
         // against 0.05-0.7 TB/s through the generic O(r^2) pass of the LDS kernel and 0.4-1.0 TB/s through
         // fourstep_mixed (tools/prime_route.py: 17 ... 2047, x1.1 ... x50)

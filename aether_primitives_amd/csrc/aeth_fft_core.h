@@ -395,6 +395,7 @@ template <int P, int S> struct BflyOddPrime {
 };
 template <int S> struct Bfly<11, S> : BflyOddPrime<11, S> {};
 template <int S> struct Bfly<13, S> : BflyOddPrime<13, S> {};
+template <int S> struct Bfly<17, S> : BflyOddPrime<17, S> {};
 
 // R = R1*R2:  X[k1 + R1*k2] = sum_n2 W_R2^(n2 k2) [ W_R^(n2 k1) sum_n1 x[n1*R2 + n2] W_R1^(n1 k1) ]
 // the inner twiddles W_R^(n2 k1) are compile-time constants held in SGPR pairs
@@ -447,6 +448,7 @@ template <int S> struct Bfly<21, S> : BflyC<7, 3, S> {};
 template <int S> struct Bfly<28, S> : BflyC<7, 4, S> {};
 template <int S> struct Bfly<22, S> : BflyC<11, 2, S> {};
 template <int S> struct Bfly<26, S> : BflyC<13, 2, S> {};
+template <int S> struct Bfly<34, S> : BflyC<17, 2, S> {};
 
 // ---- compile-time description of one transform size ---------------------------
 // WG_ = 0: the power-of-two rule (T lanes, at least 64).  WG_ > 0: that many lanes; F = WG / T frames, the

@@ -29,8 +29,15 @@ SMOOTH = sorted(({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10)
                 # ... and every 13-smooth length up to 2048 with a factor 11 or 13
                 | {2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f for a in range(12) for b in range(7) for c in range(5)
                    for d in range(4) for e in range(3) for f in range(3)
-                   if e + f >= 1 and 2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f <= 2048})
-MIXED = [1, 17, 19, 34, 61, 289, 323, 2079, 4095, 4116, 7203, 8190]           # LDS ping-pong kernel
+                   if e + f >= 1 and 2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f <= 2048}
+                # ... and every 17-smooth length up to 2048 with a factor 17 that has a decomposition of at most 34 points per lane
+                | ({17 ** g * m for g in (1, 2) for m in range(1, 121)
+                    if 17 ** g * m <= 2048 and all(m % q for q in (19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113))}
+                   - {578, 748}))
+MIXED = [1, 17, 19, 34, 61, 289, 323, 2079, 4095, 4116, 7203, 8190,           # LDS ping-pong kernel
+         # ... with its register butterflies for 11 .. 23 (beyond the one-launch chirp-z kernel's 2048), alone and mixed
+         # with a radix that still takes the O(r^2) pass (37)
+         2176, 2431, 3553, 4199, 6647, 6859, 7429, 8177]
 BIG = [8192, 32768, 65536, 1 << 17, 1 << 18, 1 << 20, 1 << 21, 1 << 22]   # 8192: one workgroup; above: four-step, every column-group width
 ODD = [67, 97, 127, 134, 1009, 4099, 5000, 6000, 10007]
 # above 8192 with two factors of at most 8192: transposes around the batched transforms of the factors
@@ -137,6 +144,8 @@ def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 100).algorithm == "stockham_mixed_ragged"
     assert HipFft(ctx, 126).algorithm == "stockham_mixed_ragged"
     assert HipFft(ctx, 143).algorithm == "stockham_mixed_ragged"
+    assert HipFft(ctx, 1700).algorithm == "stockham_mixed_ragged"      # 4 * 25 * 17: radix 17 in registers
+    assert HipFft(ctx, 578).algorithm == "bluestein"                   # 2 * 17^2: no register decomposition in the table
     assert HipFft(ctx, 323).algorithm == "bluestein"                 # 17 * 19: one-launch chirp-z beats the O(r^2) prime pass
     assert HipFft(ctx, 2 * 2057).algorithm == "stockham_mixed"       # 4114 = 2 * 11^2 * 17: too long for the one-launch kernel
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"

@@ -15,8 +15,9 @@ for n in lens:
     x = (np.random.default_rng(n).standard_normal(2 * n * batch, dtype=np.float32)).view(np.complex64)
     src = ctx.vec(x); dst = ctx.empty(n * batch)
     row = []
-    for blu in (0, 1):
+    for blu, bigr in ((0, 0), (0, 1), (1, 1)):
         os.environ['AETH_FFT_PRIME_BLU'] = str(blu)
+        os.environ['AETH_MIXED_BIGR'] = str(bigr)
         f = ap.HipFft(ctx, n, max_batch=batch)
         f.fwd(src, dst, Scale.NONE); ctx.sync()
         got = dst.to_host()[: n * min(batch, 64)].reshape(-1, n)
@@ -30,5 +31,5 @@ for n in lens:
         t = statistics.median(ts[1:])
         row.append((f.algorithm, t, evm))
         del f
-    a, b = row
-    print(f"N={n:5d} batch={batch:8d}  {a[0]:16s} {16*n*batch/a[1]/1e9:6.2f} TB/s ({a[2]:6.1f} dB)   {b[0]:10s} {16*n*batch/b[1]/1e9:6.2f} TB/s ({b[2]:6.1f} dB)   x{a[1]/b[1]:5.2f}", flush=True)
+    cols = "   ".join(f"{r[0]:14s} {16*n*batch/r[1]/1e9:5.2f} TB/s ({r[2]:6.1f} dB)" for r in row)
+    print(f"N={n:5d} batch={batch:8d}  {cols}", flush=True)
