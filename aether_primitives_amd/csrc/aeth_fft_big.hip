@@ -488,6 +488,13 @@ int fft_plan_bluestein(aeth_fft *plan)
     const size_t N = plan->len;
     size_t M = 1;
     while (M < 2 * N - 1) M <<= 1;
+    // Past the one-launch kernel (M <= 4096) the convolution length need not be a power of two: the nearest length at
+    // or above 2N-1 that one register-resident launch transforms (N = 4099: 8640 = 2^6 3^3 5 instead of 16384, half the
+    // bytes through each of the five launches).
+    if (M > 4096 && aeth::tuning_int("AETH_BLU_ANY_M", 1)) {
+        for (size_t m = 2 * N - 1; m < M; m++)
+            if (aeth::fft_ragged_supported(m)) { M = m; break; }
+    }
     plan->blu_m = M;
     int rc = aeth_fft_create(plan->ctx, M, 1, &plan->blu_sub);
     if (rc) return rc;
@@ -510,7 +517,7 @@ int fft_plan_bluestein(aeth_fft *plan)
     if (rc) return rc;
     rc = aeth_upload(plan->ctx, plan->blu_filt, filt.data(), M * sizeof(float2));
     if (rc) return rc;
-    // Bf = DFT-(b) / M : the 1/M of the inverse transform is folded in (exact, M is a power of two)
+    // Bf = DFT-(b) / M : the 1/M of the inverse transform is folded in (exact when M is a power of two)
     rc = fft_run(plan->blu_sub, plan->blu_filt, plan->blu_filt, 1, -1, 1.0f / (float)M);
     if (rc) return rc;
     return aeth_ctx_sync(plan->ctx);
