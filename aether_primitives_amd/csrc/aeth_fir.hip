@@ -311,13 +311,14 @@ int fir_exec_on(aeth_fir *f, hipStream_t stream, const aeth_cf32 *hist, const ae
 // Host-resident stream through the device in hop-aligned chunks, two slots in flight:
 // while slot A's chunk is being filtered, slot B's next chunk crosses PCIe one way and its
 // previous result the other.  The GPU-side counterpart of the reference's thread-per-stage
-// pipeline with pooled buffers (src/pipeline.rs:52-137, src/pool.rs:43-221) -- stages are
-// H2D copy | kernel | D2H copy on HIP streams, the pool is the pair of device slots.
+// pipeline with pooled buffers (src/pipeline.rs:52-137, src/pool.rs:43-221) -- the stages are H2D copy | kernel |
+// D2H copy, each on its OWN HIP stream so that both copy engines stay busy back to back; the pool is three device
+// slots, handed from stage to stage by events (no host wait inside the loop).
+constexpr int kPipeSlots = 3;
 struct PipeSlot {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
     float2 *din = nullptr, *dout = nullptr;     // device: [history | chunk], chunk
-    bool busy = false;
+    hipEvent_t up = nullptr, ran = nullptr, down = nullptr;
+    bool used = false;
 };
 
 }  // namespace
@@ -341,48 +342,68 @@ int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *
     const bool pin_in = hipHostRegister(const_cast<aeth_cf32 *>(in), n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
     const bool pin_out = hipHostRegister(out, n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
-    PipeSlot slot[2];
+    PipeSlot slot[kPipeSlots];
+    hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
     int rc = AETH_OK;
     auto fail = [&](hipError_t e, const char *what) { rc = aeth::hip_fail(e, what); };
-    for (int s = 0; s < 2 && rc == AETH_OK; s++) {
-        hipError_t e;
-        if ((e = hipStreamCreateWithFlags(&slot[s].stream, hipStreamNonBlocking)) != hipSuccess) { fail(e, "hipStreamCreate"); break; }
-        if ((e = hipEventCreateWithFlags(&slot[s].done, hipEventDisableTiming)) != hipSuccess) { fail(e, "hipEventCreate"); break; }
-        if ((e = hipMalloc((void **)&slot[s].din, (chunk + nh) * sizeof(float2))) != hipSuccess) { fail(e, "hipMalloc"); break; }
-        if ((e = hipMalloc((void **)&slot[s].dout, chunk * sizeof(float2))) != hipSuccess) { fail(e, "hipMalloc"); break; }
+    auto ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) { fail(e, what); return false; } return true; };
+    const int nslots = (int)(nchunks < (size_t)kPipeSlots ? nchunks : (size_t)kPipeSlots);
+    if (ok(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate") &&
+        ok(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking), "hipStreamCreate"))
+        (void)ok(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking), "hipStreamCreate");
+    for (int s = 0; s < nslots && rc == AETH_OK; s++) {
+        PipeSlot &sl = slot[s];
+        if (!ok(hipEventCreateWithFlags(&sl.up, hipEventDisableTiming), "hipEventCreate")) break;
+        if (!ok(hipEventCreateWithFlags(&sl.ran, hipEventDisableTiming), "hipEventCreate")) break;
+        if (!ok(hipEventCreateWithFlags(&sl.down, hipEventDisableTiming), "hipEventCreate")) break;
+        if (!ok(hipMalloc((void **)&sl.din, (chunk + nh) * sizeof(float2)), "hipMalloc")) break;
+        if (!ok(hipMalloc((void **)&sl.dout, chunk * sizeof(float2)), "hipMalloc")) break;
     }
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (rc == AETH_OK) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipStreamSynchronize(aeth::ctx_stream(ctx)); (void)hipEventRecord(t0, slot[0].stream); }
+    if (rc == AETH_OK) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipStreamSynchronize(aeth::ctx_stream(ctx)); (void)hipEventRecord(t0, s_up); }
     for (size_t k = 0; k < nchunks && rc == AETH_OK; k++) {
-        PipeSlot &sl = slot[k & 1];
+        PipeSlot &sl = slot[k % kPipeSlots];
         const size_t o0 = k * chunk;
         const size_t cnt = (n - o0 < chunk) ? n - o0 : chunk;
         const size_t h = (o0 >= nh) ? nh : o0;                     // history samples available in the source
-        hipError_t e;
-        if (sl.busy && (e = hipEventSynchronize(sl.done)) != hipSuccess) { fail(e, "hipEventSynchronize"); break; }
+        // H2D: the slot's input buffer is free once the kernel of chunk k - 3 has run
+        if (sl.used && !ok(hipStreamWaitEvent(s_up, sl.ran, 0), "hipStreamWaitEvent")) break;
         // [zeros | history | chunk] -> device; the filter reads its history straight from the source slice
-        if (h < nh && (e = hipMemsetAsync(sl.din, 0, (nh - h) * sizeof(float2), sl.stream)) != hipSuccess) { fail(e, "hipMemsetAsync"); break; }
-        if ((e = hipMemcpyAsync(sl.din + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), hipMemcpyHostToDevice, sl.stream)) != hipSuccess) { fail(e, "hipMemcpyAsync H2D"); break; }
-        rc = fir_exec_on(f, sl.stream, o0 ? (const aeth_cf32 *)sl.din : nullptr, (const aeth_cf32 *)(sl.din + nh), cnt, (aeth_cf32 *)sl.dout);
+        if (h < nh && !ok(hipMemsetAsync(sl.din, 0, (nh - h) * sizeof(float2), s_up), "hipMemsetAsync")) break;
+        if (!ok(hipMemcpyAsync(sl.din + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
+        if (!ok(hipEventRecord(sl.up, s_up), "hipEventRecord")) break;
+        // kernel: needs the chunk up and the slot's output buffer drained by the D2H of chunk k - 3
+        if (!ok(hipStreamWaitEvent(s_run, sl.up, 0), "hipStreamWaitEvent")) break;
+        if (sl.used && !ok(hipStreamWaitEvent(s_run, sl.down, 0), "hipStreamWaitEvent")) break;
+        rc = fir_exec_on(f, s_run, o0 ? (const aeth_cf32 *)sl.din : nullptr, (const aeth_cf32 *)(sl.din + nh), cnt, (aeth_cf32 *)sl.dout);
         if (rc) break;
-        if ((e = hipMemcpyAsync(out + o0, sl.dout, cnt * sizeof(float2), hipMemcpyDeviceToHost, sl.stream)) != hipSuccess) { fail(e, "hipMemcpyAsync D2H"); break; }
-        if ((e = hipEventRecord(sl.done, sl.stream)) != hipSuccess) { fail(e, "hipEventRecord"); break; }
-        sl.busy = true;
+        if (!ok(hipEventRecord(sl.ran, s_run), "hipEventRecord")) break;
+        // D2H
+        if (!ok(hipStreamWaitEvent(s_down, sl.ran, 0), "hipStreamWaitEvent")) break;
+        if (!ok(hipMemcpyAsync(out + o0, sl.dout, cnt * sizeof(float2), hipMemcpyDeviceToHost, s_down), "hipMemcpyAsync D2H")) break;
+        if (!ok(hipEventRecord(sl.down, s_down), "hipEventRecord")) break;
+        sl.used = true;
     }
-    for (int s = 0; s < 2; s++) if (slot[s].stream) (void)hipStreamSynchronize(slot[s].stream);
+    if (s_up) (void)hipStreamSynchronize(s_up);
+    if (s_run) (void)hipStreamSynchronize(s_run);
+    if (s_down) (void)hipStreamSynchronize(s_down);
     if (rc == AETH_OK && stats && t0 && t1) {
-        // both slot streams are idle now; time from the first enqueue to here
-        (void)hipEventRecord(t1, slot[0].stream); (void)hipEventSynchronize(t1);
+        // all three stage streams are idle now; time from the first enqueue to here
+        (void)hipEventRecord(t1, s_down); (void)hipEventSynchronize(t1);
         float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1);
         stats->seconds = ms * 1e-3; stats->samples = (double)n; stats->chunks = (double)nchunks;
         stats->pinned = (pin_in ? 1 : 0) + (pin_out ? 2 : 0);
     }
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < kPipeSlots; s++) {
         if (slot[s].din) (void)hipFree(slot[s].din);
         if (slot[s].dout) (void)hipFree(slot[s].dout);
-        if (slot[s].done) (void)hipEventDestroy(slot[s].done);
-        if (slot[s].stream) (void)hipStreamDestroy(slot[s].stream);
+        if (slot[s].up) (void)hipEventDestroy(slot[s].up);
+        if (slot[s].ran) (void)hipEventDestroy(slot[s].ran);
+        if (slot[s].down) (void)hipEventDestroy(slot[s].down);
     }
+    if (s_up) (void)hipStreamDestroy(s_up);
+    if (s_run) (void)hipStreamDestroy(s_run);
+    if (s_down) (void)hipStreamDestroy(s_down);
     if (t0) (void)hipEventDestroy(t0);
     if (t1) (void)hipEventDestroy(t1);
     if (pin_in) (void)hipHostUnregister(const_cast<aeth_cf32 *>(in));

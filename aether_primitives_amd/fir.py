@@ -63,7 +63,7 @@ class Fir:
         return out
 
     def filter_file(self, in_path, out_path, chunk=0):
-        """raw cf32 file -> FIR -> raw cf32 file (util::file format), through the double-buffered pipeline."""
+        """raw cf32 file -> FIR -> raw cf32 file (util::file format), through the three-stage stream pipeline."""
         import os
 
         class _Stats(C.Structure):
@@ -73,7 +73,7 @@ class Fir:
         return {"seconds": st.seconds, "samples": st.samples, "chunks": st.chunks, "pinned": st.pinned}
 
     def filter_stream(self, x, out=None, chunk=0):
-        """Host array through the device in double-buffered hop-aligned chunks (PCIe-rate path).
+        """Host array through the device in hop-aligned chunks, upload | kernel | download on three streams (PCIe-rate path).
         Returns (y, stats) with stats = dict(seconds, samples, chunks, pinned)."""
         x = np.ascontiguousarray(x, dtype=np.complex64)
         if out is None:

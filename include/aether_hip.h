@@ -220,8 +220,9 @@ AETH_API int aeth_fir_exec_host(aeth_fir *fir, const aeth_cf32 *hist_host, const
                                 size_t n, aeth_cf32 *out_host);
 
 /* Host-resident stream through the device at PCIe rate (SURVEY 8f "next" #4): hop-aligned
- * chunks, two device slots on two HIP streams so that the H2D copy of chunk k+1, the kernel
- * on chunk k and the D2H copy of chunk k-1 overlap -- the device-side counterpart of the
+ * chunks, three device slots handed by events between an upload, a kernel and a download stream, so
+ * that the H2D copy of chunk k+1, the kernel on chunk k and the D2H copy of chunk k-1 overlap and
+ * both copy engines run back to back -- the device-side counterpart of the
  * reference's thread-per-stage pipeline over pooled buffers (src/pipeline.rs:52-137,
  * src/pool.rs:43-221).  Output is bit-identical to aeth_fir_exec_host on the whole slice.
  * chunk_samples = 0 picks 4 Mi samples.  stats may be NULL. */
