@@ -308,10 +308,9 @@ int fir_exec_on(aeth_fir *f, hipStream_t stream, const aeth_cf32 *hist, const ae
     return dispatch_fmi(f->ctx, f->fft_len, a, stream);
 }
 
-// Host-resident stream through the device in hop-aligned chunks, two slots in flight:
-// while slot A's chunk is being filtered, slot B's next chunk crosses PCIe one way and its
-// previous result the other.  The GPU-side counterpart of the reference's thread-per-stage
-// pipeline with pooled buffers (src/pipeline.rs:52-137, src/pool.rs:43-221) -- the stages are H2D copy | kernel |
+// Host-resident stream through the device in hop-aligned chunks: while one chunk is being filtered the next
+// crosses PCIe one way and the previous result the other.  The GPU-side counterpart of the reference's
+// thread-per-stage pipeline with pooled buffers (src/pipeline.rs:52-137, src/pool.rs:43-221) -- the stages are H2D copy | kernel |
 // D2H copy, each on its OWN HIP stream so that both copy engines stay busy back to back; the pool is three device
 // slots, handed from stage to stage by events (no host wait inside the loop).
 constexpr int kPipeSlots = 3;
@@ -321,11 +320,9 @@ struct PipeSlot {
     bool used = false;
 };
 
-}  // namespace
 
-extern "C" {
-
-int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
+// hist: ntaps-1 host samples in front of `in` (null: zeros), as in aeth_fir_exec_host
+int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
 {
     AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
     if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0};
@@ -369,13 +366,14 @@ int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *
         // H2D: the slot's input buffer is free once the kernel of chunk k - 3 has run
         if (sl.used && !ok(hipStreamWaitEvent(s_up, sl.ran, 0), "hipStreamWaitEvent")) break;
         // [zeros | history | chunk] -> device; the filter reads its history straight from the source slice
-        if (h < nh && !ok(hipMemsetAsync(sl.din, 0, (nh - h) * sizeof(float2), s_up), "hipMemsetAsync")) break;
+        if (k == 0 && hist && nh) { if (!ok(hipMemcpyAsync(sl.din, hist, nh * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break; }
+        else if (h < nh && !ok(hipMemsetAsync(sl.din, 0, (nh - h) * sizeof(float2), s_up), "hipMemsetAsync")) break;
         if (!ok(hipMemcpyAsync(sl.din + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
         if (!ok(hipEventRecord(sl.up, s_up), "hipEventRecord")) break;
         // kernel: needs the chunk up and the slot's output buffer drained by the D2H of chunk k - 3
         if (!ok(hipStreamWaitEvent(s_run, sl.up, 0), "hipStreamWaitEvent")) break;
         if (sl.used && !ok(hipStreamWaitEvent(s_run, sl.down, 0), "hipStreamWaitEvent")) break;
-        rc = fir_exec_on(f, s_run, o0 ? (const aeth_cf32 *)sl.din : nullptr, (const aeth_cf32 *)(sl.din + nh), cnt, (aeth_cf32 *)sl.dout);
+        rc = fir_exec_on(f, s_run, (o0 || hist) ? (const aeth_cf32 *)sl.din : nullptr, (const aeth_cf32 *)(sl.din + nh), cnt, (aeth_cf32 *)sl.dout);
         if (rc) break;
         if (!ok(hipEventRecord(sl.ran, s_run), "hipEventRecord")) break;
         // D2H
@@ -409,6 +407,15 @@ int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *
     if (pin_in) (void)hipHostUnregister(const_cast<aeth_cf32 *>(in));
     if (pin_out) (void)hipHostUnregister(out);
     return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
+{
+    return fir_stream_host(f, nullptr, in, n, out, chunk, stats);
 }
 
 int aeth_fir_exec_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out)

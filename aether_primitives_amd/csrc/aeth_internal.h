@@ -27,9 +27,7 @@ struct aeth_ctx {
     bool aux_pending = false;      // the aux lane holds work the main stream is not yet ordered behind
     int chain_last = -1;           // lane of the latest FIR launch while nothing else has been enqueued since; else -1
     uintptr_t last_in[2] = {0, 0}, last_out[2] = {0, 0};   // [lo, hi) byte ranges of that launch
-    // staging for the host-slice flavours: pinned host + device scratch, grown on demand
-    void *pin[2] = {nullptr, nullptr};
-    size_t pin_bytes[2] = {0, 0};
+    // device scratch of the host-slice flavours, grown on demand
     void *stage[2] = {nullptr, nullptr};
     size_t stage_bytes[2] = {0, 0};
 };
@@ -47,7 +45,7 @@ inline hipStream_t ctx_stream(const aeth_ctx *ctx) { return ctx_stream(const_cas
 // previous call on this context was such a launch and the buffers are disjoint, else the main stream.
 hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintptr_t out_lo, uintptr_t out_hi);
 
-// ensure staging slot `i` holds >= bytes (device + pinned host)
+// ensure staging slot `i` holds >= bytes of device memory
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes);
 
 // Tuning knobs (tools/tune_*.py): environment integers that are consulted ONLY when the

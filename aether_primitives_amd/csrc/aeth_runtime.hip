@@ -100,12 +100,6 @@ int ctx_stage(aeth_ctx *ctx, int i, size_t bytes)
         AETH_HIP(hipMalloc(&ctx->stage[i], want));
         ctx->stage_bytes[i] = want;
     }
-    if (ctx->pin_bytes[i] < bytes) {
-        size_t want = bytes + bytes / 4;
-        if (ctx->pin[i]) { AETH_HIP(hipHostFree(ctx->pin[i])); ctx->pin[i] = nullptr; ctx->pin_bytes[i] = 0; }
-        AETH_HIP(hipHostMalloc(&ctx->pin[i], want, hipHostMallocDefault));
-        ctx->pin_bytes[i] = want;
-    }
     return AETH_OK;
 }
 
@@ -201,7 +195,6 @@ int aeth_ctx_destroy(aeth_ctx *ctx)
     overlap_release(ctx);
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
-        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
     }
     if (ctx->owns_stream && ctx->stream_main) (void)hipStreamDestroy(ctx->stream_main);
     delete ctx;
