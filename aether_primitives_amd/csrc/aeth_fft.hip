@@ -18,7 +18,7 @@
 //                   vecops.rs:443-463 at N=100), generic O(r^2) for other primes.
 //   fourstep_mixed  N > 8192 = n1 * n2 with both factors <= 8192: three transposes around
 //                   the batched transforms of the factors (aeth_fft_big.hip).
-//   fourstep_pow2   N = 2^13..2^24: N1 x N2 decomposition, two launches through the
+//   fourstep_pow2   N = 2^13..2^23 (2^24: fourstep_mixed): N1 x N2 decomposition, two launches through the
 //                   plan's scratch (BASELINE config 5, N = 65536 = 256 x 256).
 //   bluestein       everything else: chirp-z through a power-of-two convolution.
 #include "aeth_internal.h"

@@ -1,6 +1,6 @@
 // aeth_fft_big.hip -- transforms that do not fit one workgroup's LDS.
 //
-// fourstep_pow2 (N = 2^13 .. 2^24, BASELINE config 5 uses 65536 = 256 x 256):
+// fourstep_pow2 (N = 2^13 .. 2^23, BASELINE config 5 uses 65536 = 256 x 256):
 //   x[n1*N2 + n2]  --A-->  a[k1*N2 + n2] = W_N^(n2*k1) * sum_n1 x[n1*N2+n2] W_N1^(n1*k1)
 //                  --B-->  X[k1 + N1*k2] = sum_n2 a[k1*N2+n2] W_N2^(n2*k2)
 //   A: a workgroup owns G adjacent columns (G*8 B contiguous per row: 128 B for G=16),
@@ -49,23 +49,23 @@ template <class C> constexpr int group_of()
 }
 
 // columns per workgroup of step A: GW wanted (16 = 128-byte segments, 32 = 256-byte), fewer when lanes or LDS run out
-template <class C, int GW> constexpr int col_group_of()
+template <class C, int GW, int MAXL = 1024> constexpr int col_group_of()
 {
     int g = GW;
-    while (g > 1 && (g * C::T > 1024 || g * col_stride<C>() * 8 > AETH_4S_LDS_LIMIT)) g /= 2;
+    while (g > 1 && (g * C::T > MAXL || g * col_stride<C>() * 8 > AETH_4S_LDS_LIMIT)) g /= 2;
     return g;
 }
 
 // ---- step A: G columns per workgroup ---------------------------------------------
 // NT: x is read / X is written with the non-temporal hint, which leaves L2 and the Infinity Cache to the
 // intermediate (batch 512 x 65536: 212 -> 159 us); small batches that fit the cache whole do better without
-template <class C0, int S, bool NT, int GW = 16>
-__global__ __launch_bounds__((col_group_of<C0, GW>()) * C0::T) void fourstep_cols(const cf *in, cf *work,
+template <class C0, int S, bool NT, int GW = 16, int MAXL = 1024>
+__global__ __launch_bounds__((col_group_of<C0, GW, MAXL>()) * C0::T) void fourstep_cols(const cf *in, cf *work,
                                                                           const cf *__restrict__ twL1,
                                                                           const cf *__restrict__ twN, int N2, size_t N)
 {
     using C = OneImage<C0>;
-    constexpr int G = col_group_of<C0, GW>();
+    constexpr int G = col_group_of<C0, GW, MAXL>();
     constexpr int CS = col_stride<C0>();
     __shared__ cf lds_all[G * CS > 0 ? G * CS : 1];
     const int col = threadIdx.x % G;
@@ -161,10 +161,14 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_tot
     // 32 adjacent columns per workgroup (256-byte segments) where lanes and LDS allow (n1 <= 256): 512 x 65536 runs in
     // 169 us against 177 us with 16 (tools/tune_4step.py, AETH_4S_COLG), no difference on small batches
     const bool wide = aeth::tuning_int("AETH_4S_COLG", 32) >= 32 && col_group_of<C, 32>() == 32 && plan->n2 % 32 == 0;
-    const int G = wide ? 32 : col_group_of<C, 16>();
+    // columns of 1024 points and more (64+ lanes each): 16 of them make a 1024-lane workgroup, which caps the kernel at
+    // 128 VGPRs and spills 22-28 of them; 8 columns (512 lanes, 256 VGPRs, 64-byte row segments) is the alternative
+    const bool half = !wide && C::T >= 64 && aeth::tuning_int("AETH_4S_MAXL", 1024) <= 512;
+    const int G = wide ? 32 : half ? col_group_of<C, 16, 512>() : col_group_of<C, 16>();
     const size_t grid = batch * (plan->n2 / G);
     auto kern = wide ? (nt ? fourstep_cols<C, S, true, 32> : fourstep_cols<C, S, false, 32>)
-                     : (nt ? fourstep_cols<C, S, true, 16> : fourstep_cols<C, S, false, 16>);
+                : half ? (nt ? fourstep_cols<C, S, true, 16, 512> : fourstep_cols<C, S, false, 16, 512>)
+                       : (nt ? fourstep_cols<C, S, true, 16> : fourstep_cols<C, S, false, 16>);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
                        (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
                        aeth::tuning_int("AETH_4S_NOTW", 0) ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
@@ -382,9 +386,22 @@ int fft_plan_fourstep(aeth_fft *plan)
 {
     int k = 0;
     while (((size_t)1 << k) < plan->len) k++;
+    // The split (tools/vs_rocfft.py under AETH_4S_N1LOG, 32 Mi samples): step B scatters one 8-byte element per row, so
+    // it needs many short rows per workgroup -- rows of 4096 points run at 0.6-0.8 TB/s, rows of 2048 and fewer at
+    // 2-3 TB/s -- while step A loses its 128-byte row segments once a column needs more than 64 lanes (n1 > 1024).
+    // So: 256 columns up to 2^18, rows of 2048 from 2^19 (2^19 as 256 x 2048: 2.18 -> 2.48 TB/s, 2^20 as 512 x 2048:
+    // 1.73 -> 2.13 TB/s against the square split, 2^23 as 4096 x 2048: 1052 -> 661 us); 2^24 has no such split and
+    // goes through the transposing path instead (aeth_fft_create; 1220 -> 975 us).
     plan->n1 = (size_t)1 << (k / 2);
+    if (k >= 16 && k <= 18) plan->n1 = 256;
+    else if (k >= 19 && k <= 23) plan->n1 = (size_t)1 << (k - 11);
+    // deep form (fft_run_fourstep): n1 <= 256 columns over rows of 65536 points that are four-step transforms themselves
+    const int deep_from = aeth::tuning_int("AETH_4S_DEEP_FROM", 23);
+    if (k >= deep_from && k >= 21) plan->n1 = (size_t)1 << (k - 16);
+    const int n1log = aeth::tuning_int("AETH_4S_N1LOG", 0);
+    if (n1log >= 4 && n1log < k && k - n1log <= 12) plan->n1 = (size_t)1 << n1log;
     plan->n2 = plan->len / plan->n1;
-    if (plan->n1 < 16 || plan->n2 > 4096) return set_error(AETH_E_UNSUPPORTED, "fourstep_pow2: length %zu", plan->len);
+    if (plan->n1 < 16 || (plan->n2 > 4096 && plan->n2 != 65536)) return set_error(AETH_E_UNSUPPORTED, "fourstep_pow2: length %zu", plan->len);
     int rc = aeth_fft_create(plan->ctx, plan->n1, 1, &plan->sub1);
     if (rc) return rc;
     return aeth_fft_create(plan->ctx, plan->n2, 1, &plan->sub2);
@@ -420,6 +437,16 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
 #undef AETH_BODY
         rc = cols();
         if (rc) return rc;
+        if (plan->n2 > 4096) {
+            // deep form: the n1 rows of a frame are n2-point transforms of their own (natural order, in place in the
+            // work buffer, two launches), and X[k1 + n1 k2] is their transpose -- four launches of 16 B/sample each,
+            // every one with 256-byte row segments, where the two-launch form would store 16-byte segments
+            rc = fft_run(plan->sub2, plan->work_dev, plan->work_dev, cnt * plan->n1, sign, scale);
+            if (rc) return rc;
+            rc = launch_transpose<0>(plan, plan->work_dev, gout, plan->n1, plan->n2, cnt);
+            if (rc) return rc;
+            continue;
+        }
         rc = rows();
         if (rc) return rc;
     }

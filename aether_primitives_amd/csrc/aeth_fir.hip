@@ -72,8 +72,11 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     }
     if constexpr (C::F == 1 && !SCALED) {
         if (b.dec.d > 1) {                                  // decimating store (aeth_fir_exec_decim)
-            if (nt) hipLaunchKernelGGL((fmi_kernel<C, false, 1, true, false, VAR | V_DECIM>), dim3(grid), dim3(C::WG), 0, stream, b);
-            else hipLaunchKernelGGL((fmi_kernel<C, false, 1, false, false, VAR | V_DECIM>), dim3(grid), dim3(C::WG), 0, stream, b);
+            // without the swizzle: with it the N = 2048 build needs 260 VGPRs and drops to one wave per SIMD (62 us
+            // per 16 Mi-sample launch against 50)
+            constexpr int DV = (VAR & ~V_XOR) | V_DECIM;
+            if (nt) hipLaunchKernelGGL((fmi_kernel<C, false, 2, true, false, DV>), dim3(grid), dim3(C::WG), 0, stream, b);
+            else hipLaunchKernelGGL((fmi_kernel<C, false, 2, false, false, DV>), dim3(grid), dim3(C::WG), 0, stream, b);
             AETH_HIP(hipGetLastError());
             return AETH_OK;
         }

@@ -168,8 +168,8 @@ def test_downsample_source_beyond_4gib(ctx, oracle):
 
 @pytest.mark.parametrize("logn", [23, 24])
 def test_fourstep_largest_lengths(ctx, oracle, logn):
-    """2^23 and 2^24 points (n2 = 4096: the Cfg<4096> column / row kernels with 2 columns per workgroup) in place and
-    out of place against the f64 truth (advertised but untested)."""
+    """2^23 and 2^24 points (the deep form: 128 / 256 columns over rows of 65536 points that are four-step transforms
+    themselves, then a transpose) in place and out of place against the f64 truth (advertised but untested)."""
     n = 1 << logn
     x = rand_c64(logn, n)
     f = HipFft(ctx, n)

@@ -104,7 +104,7 @@ for dec in (4, 16):
     dd = ctx.empty(half // dec)
     report(f"fir + decimating store dec={dec} (16 Mi in)", 8 * half + 8 * half // dec, timeit(lambda i: fir.filter_decim(A[i % NB].slice(0, half), dec, out=dd)), half)
 report("fft + mirror epilogue N=2048", 16 * n, timeit(lambda i: f.rfft_mirror(A[i % NB], Scale.SN)), n)
-for N in (17, 61, 323, 1003, 2006):
+for N in (17, 85, 1700, 61, 323, 1003, 2006, 2176, 4199):
     fp = ap.HipFft(ctx, N); m = (n // N) * N
     report(f"fft ifwd N={N} batch={m // N} ({fp.algorithm})", 16 * m, timeit(lambda i: fp.ifwd(A[i % NB].slice(0, m), Scale.SN)), m)
 json.dump(rows, open("gpurun_out/kernel_survey.json", "w"), indent=1)
