@@ -747,7 +747,9 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
         p->algo = aeth::FFT_ALGO_MIXED;      // zero passes: copy + scale
         p->factors.clear();
         p->algo_name = "identity";
-    } else if (is_pow2(len) && len <= 8192) {
+    } else if (is_pow2(len) && (len <= 4096 || (len == 8192 && (!aeth::fft_ragged_supported(len) || aeth::tuning_int("AETH_FFT_NORAGGED", 0))))) {
+        // 8192 itself has a row in the ragged table (256 lanes x 32 points, radices 32 32 8, unpadded image: 102 us
+        // per 32 Mi samples against 124 us for the 512-lane x 16-point kernel here, which spills at two waves per SIMD)
         p->algo = aeth::FFT_ALGO_POW2;
         p->algo_name = "stockham_pow2";
     } else if (aeth::fft_ragged_supported(len) && !aeth::tuning_int("AETH_FFT_NORAGGED", 0)) {

@@ -20,10 +20,10 @@ KAT = load_kat()
 TOL_DB = -120.0
 
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
-# the ragged register-resident table: every length 2^a 3^b 5^c up to 20480 that is no power of two, 16384, and every
+# the ragged register-resident table: every length 2^a 3^b 5^c up to 20480 that is no power of two, 8192, 16384, and every
 # length 2^a 3^b 5^c 7^d up to 4096 with d >= 1
 SMOOTH = sorted(({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10) for c in range(7)
-                  if 3 <= 2 ** a * 3 ** b * 5 ** c <= 20480} - {2 ** k for k in range(15)}) | {16384}
+                  if 3 <= 2 ** a * 3 ** b * 5 ** c <= 20480} - {2 ** k for k in range(15)}) | {8192, 16384}
                 | {2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(13) for b in range(8) for c in range(6) for d in range(1, 5)
                    if 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096}
                 # ... and every 13-smooth length up to 2048 with a factor 11 or 13
