@@ -325,9 +325,13 @@ struct PipeSlot {
 
 
 // hist: ntaps-1 host samples in front of `in` (null: zeros), as in aeth_fir_exec_host
-int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
+// util: per-stage active time as well (the device-side counterpart of the reference's per-stage utilisation
+// report, src/pipeline.rs:89-114): timed events around every stage operation, read back after the run
+int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats,
+                    aeth_pipe_util *util = nullptr)
 {
     AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
+    if (util) *util = aeth_pipe_util{0, 0, 0, 0, 0, 0, 0};
     if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0};
     if (n == 0) return AETH_OK;
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
@@ -361,6 +365,15 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
     }
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (rc == AETH_OK) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipStreamSynchronize(aeth::ctx_stream(ctx)); (void)hipEventRecord(t0, s_up); }
+    // [chunk][stage][begin, end] -- only when the utilisation report is wanted
+    std::vector<hipEvent_t> marks;
+    if (util && rc == AETH_OK) {
+        marks.assign(nchunks * 6, nullptr);
+        for (auto &m : marks) if (!ok(hipEventCreate(&m), "hipEventCreate")) break;
+    }
+    auto mark = [&](size_t k, int stage, int end, hipStream_t st) {
+        if (!marks.empty() && rc == AETH_OK) (void)ok(hipEventRecord(marks[k * 6 + stage * 2 + end], st), "hipEventRecord");
+    };
     for (size_t k = 0; k < nchunks && rc == AETH_OK; k++) {
         PipeSlot &sl = slot[k % kPipeSlots];
         const size_t o0 = k * chunk;
@@ -368,33 +381,51 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
         const size_t h = (o0 >= nh) ? nh : o0;                     // history samples available in the source
         // H2D: the slot's input buffer is free once the kernel of chunk k - 3 has run
         if (sl.used && !ok(hipStreamWaitEvent(s_up, sl.ran, 0), "hipStreamWaitEvent")) break;
+        mark(k, 0, 0, s_up);
         // [zeros | history | chunk] -> device; the filter reads its history straight from the source slice
         if (k == 0 && hist && nh) { if (!ok(hipMemcpyAsync(sl.din, hist, nh * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break; }
         else if (h < nh && !ok(hipMemsetAsync(sl.din, 0, (nh - h) * sizeof(float2), s_up), "hipMemsetAsync")) break;
         if (!ok(hipMemcpyAsync(sl.din + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
+        mark(k, 0, 1, s_up);
         if (!ok(hipEventRecord(sl.up, s_up), "hipEventRecord")) break;
         // kernel: needs the chunk up and the slot's output buffer drained by the D2H of chunk k - 3
         if (!ok(hipStreamWaitEvent(s_run, sl.up, 0), "hipStreamWaitEvent")) break;
         if (sl.used && !ok(hipStreamWaitEvent(s_run, sl.down, 0), "hipStreamWaitEvent")) break;
+        mark(k, 1, 0, s_run);
         rc = fir_exec_on(f, s_run, (o0 || hist) ? (const aeth_cf32 *)sl.din : nullptr, (const aeth_cf32 *)(sl.din + nh), cnt, (aeth_cf32 *)sl.dout);
         if (rc) break;
+        mark(k, 1, 1, s_run);
         if (!ok(hipEventRecord(sl.ran, s_run), "hipEventRecord")) break;
         // D2H
         if (!ok(hipStreamWaitEvent(s_down, sl.ran, 0), "hipStreamWaitEvent")) break;
+        mark(k, 2, 0, s_down);
         if (!ok(hipMemcpyAsync(out + o0, sl.dout, cnt * sizeof(float2), hipMemcpyDeviceToHost, s_down), "hipMemcpyAsync D2H")) break;
+        mark(k, 2, 1, s_down);
         if (!ok(hipEventRecord(sl.down, s_down), "hipEventRecord")) break;
         sl.used = true;
     }
     if (s_up) (void)hipStreamSynchronize(s_up);
     if (s_run) (void)hipStreamSynchronize(s_run);
     if (s_down) (void)hipStreamSynchronize(s_down);
-    if (rc == AETH_OK && stats && t0 && t1) {
+    if (rc == AETH_OK && (stats || util) && t0 && t1) {
         // all three stage streams are idle now; time from the first enqueue to here
         (void)hipEventRecord(t1, s_down); (void)hipEventSynchronize(t1);
         float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1);
-        stats->seconds = ms * 1e-3; stats->samples = (double)n; stats->chunks = (double)nchunks;
-        stats->pinned = (pin_in ? 1 : 0) + (pin_out ? 2 : 0);
+        const double pinned = (pin_in ? 1 : 0) + (pin_out ? 2 : 0);
+        if (stats) { stats->seconds = ms * 1e-3; stats->samples = (double)n; stats->chunks = (double)nchunks; stats->pinned = pinned; }
+        if (util) {
+            util->seconds = ms * 1e-3; util->samples = (double)n; util->chunks = (double)nchunks; util->pinned = pinned;
+            double act[3] = {0, 0, 0};
+            for (size_t k = 0; k < nchunks && !marks.empty(); k++)
+                for (int st = 0; st < 3; st++) {
+                    float d = 0;
+                    if (hipEventElapsedTime(&d, marks[k * 6 + st * 2], marks[k * 6 + st * 2 + 1]) == hipSuccess) act[st] += d * 1e-3;
+                }
+            (void)hipGetLastError();
+            util->active_upload = act[0]; util->active_kernel = act[1]; util->active_download = act[2];
+        }
     }
+    for (auto m : marks) if (m) (void)hipEventDestroy(m);
     for (int s = 0; s < kPipeSlots; s++) {
         if (slot[s].din) (void)hipFree(slot[s].din);
         if (slot[s].dout) (void)hipFree(slot[s].dout);
@@ -419,6 +450,12 @@ extern "C" {
 int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
 {
     return fir_stream_host(f, nullptr, in, n, out, chunk, stats);
+}
+
+int aeth_fir_stream_host_util(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_util *util)
+{
+    AETH_REQUIRE(util, AETH_E_ARG, "util is null");
+    return fir_stream_host(f, nullptr, in, n, out, chunk, nullptr, util);
 }
 
 int aeth_fir_exec_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out)

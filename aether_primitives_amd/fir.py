@@ -72,12 +72,24 @@ class Fir:
         check(self._lib.aeth_fir_stream_file(self.h, os.fsencode(in_path), os.fsencode(out_path), chunk, C.byref(st)))
         return {"seconds": st.seconds, "samples": st.samples, "chunks": st.chunks, "pinned": st.pinned}
 
-    def filter_stream(self, x, out=None, chunk=0):
+    def filter_stream(self, x, out=None, chunk=0, report=False):
         """Host array through the device in hop-aligned chunks, upload | kernel | download on three streams (PCIe-rate path).
-        Returns (y, stats) with stats = dict(seconds, samples, chunks, pinned)."""
+        Returns (y, stats) with stats = dict(seconds, samples, chunks, pinned); report=True adds the seconds each stage
+        was active and `lines`, the reference pipeline's per-stage report (pipeline.rs:101-108) for the three stages."""
         x = np.ascontiguousarray(x, dtype=np.complex64)
         if out is None:
             out = np.empty_like(x)
+        if report:
+            class _Util(C.Structure):
+                _fields_ = [(k, C.c_double) for k in ("seconds", "samples", "chunks", "pinned", "active_upload", "active_kernel", "active_download")]
+            u = _Util()
+            check(self._lib.aeth_fir_stream_host_util(self.h, x.ctypes.data_as(C.c_void_p), x.size,
+                                                      out.ctypes.data_as(C.c_void_p), chunk, C.byref(u)))
+            st = {k: getattr(u, k) for k, _ in _Util._fields_}
+            st["lines"] = [f"Stage: {name:15} : Processed {int(u.chunks)} in {u.seconds:3.3f}s ({u.chunks / u.seconds:9.2f}/s); "
+                           f"Utilisation: {act / u.seconds * 100.0:3.2f}%"
+                           for name, act in (("upload", u.active_upload), ("kernel", u.active_kernel), ("download", u.active_download))]
+            return out, st
 
         class _Stats(C.Structure):
             _fields_ = [("seconds", C.c_double), ("samples", C.c_double), ("chunks", C.c_double), ("pinned", C.c_double)]

@@ -229,6 +229,12 @@ AETH_API int aeth_fir_exec_host(aeth_fir *fir, const aeth_cf32 *hist_host, const
 typedef struct { double seconds, samples, chunks, pinned; } aeth_pipe_stats;
 AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
                                   size_t chunk_samples, aeth_pipe_stats *stats);
+/* The same run with the per-stage report of the reference's pipeline (src/pipeline.rs:89-114: items processed, rate and
+ * "Utilisation" = time active / time elapsed, per stage): seconds each of the three stages -- upload, kernel, download --
+ * was busy, from timed events around every stage operation.  Utilisation of a stage = active_x / seconds. */
+typedef struct { double seconds, samples, chunks, pinned, active_upload, active_kernel, active_download; } aeth_pipe_util;
+AETH_API int aeth_fir_stream_host_util(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
+                                       size_t chunk_samples, aeth_pipe_util *util);
 
 /* ---- raw sample files (SURVEY 8f "next" #3): src/util/file.rs:12-107 ------------------------ */
 /* The reference's binary files are header-less native-endian dumps of back-to-back structs;

@@ -10,6 +10,12 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 /// aeth_pipe_stats: what the double-buffered host-stream pipeline reports
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct aeth_pipe_stats { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64 }
+/// aeth_pipe_util: the same plus the seconds each stage (upload, kernel, download) was active -- the per-stage
+/// utilisation report of src/pipeline.rs:89-114
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct aeth_pipe_util { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64,
+                            pub active_upload: f64, pub active_kernel: f64, pub active_download: f64 }
 
 pub const AETH_OK: c_int = 0;
 pub const AETH_E_LEN: c_int = -1;
@@ -103,6 +109,8 @@ extern "C" {
     pub fn aeth_fir_hop(fir: *const aeth_fir) -> usize;
     pub fn aeth_fir_stream_host(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,
                                 stats: *mut aeth_pipe_stats) -> c_int;
+    pub fn aeth_fir_stream_host_util(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,
+                                     util: *mut aeth_pipe_util) -> c_int;
     pub fn aeth_fir_stream_file(fir: *mut aeth_fir, in_path: *const c_char, out_path: *const c_char, chunk: usize,
                                 stats: *mut aeth_pipe_stats) -> c_int;
     pub fn aeth_file_count_structs(path: *const c_char, elem_size: usize, count: *mut usize) -> c_int;

@@ -177,6 +177,17 @@ impl<'c> Fir<'c> {
         check(unsafe { aeth_fir_stream_host(self.h, x.as_ptr(), x.len(), y.as_mut_ptr(), 0, &mut st) });
         st
     }
+    /// the same run, printing the reference pipeline's per-stage report (src/pipeline.rs:101-108) for the three device stages
+    pub fn filter_stream_report(&mut self, x: &[cf32], y: &mut [cf32]) -> aeth_pipe_util {
+        assert_eq!(x.len(), y.len(), "Vectors must have same length");
+        let mut u = aeth_pipe_util::default();
+        check(unsafe { aeth_fir_stream_host_util(self.h, x.as_ptr(), x.len(), y.as_mut_ptr(), 0, &mut u) });
+        for (name, active) in [("upload", u.active_upload), ("kernel", u.active_kernel), ("download", u.active_download)].iter() {
+            println!("Stage: {:15} : Processed {} in {:3.3}s ({:9.2}/s); Utilisation: {:3.2}%",
+                     name, u.chunks as u64, u.seconds, u.chunks / u.seconds, active / u.seconds * 100.0);
+        }
+        u
+    }
 }
 impl<'c> Drop for Fir<'c> { fn drop(&mut self) { unsafe { aeth_fir_destroy(self.h); } } }
 

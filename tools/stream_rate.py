@@ -21,5 +21,7 @@ for n in (64 << 20, 256 << 20):
             y, st = fir.filter_stream(x, chunk=chunk)
             if best is None or st["seconds"] < best["seconds"]: best = st
         same = "" if ref is None else ("  bit-identical" if np.array_equal(y.view(np.uint32), ref.view(np.uint32)) else "  MISMATCH")
+        if chunk == 4 << 20:
+            for l in fir.filter_stream(x, chunk=chunk, report=True)[1]["lines"]: print("      " + l)
         print(f"n = {n >> 20:4d} Mi  chunk {chunk >> 20:3d} Mi samples ({chunk >> 17:4d} MiB)  {best['seconds'] * 1e3:8.2f} ms  "
               f"{n / best['seconds'] / 1e9:5.2f} GS/s  {8 * n / best['seconds'] / 1e9:5.1f} GB/s per direction  pinned={int(best['pinned'])}{same}", flush=True)
