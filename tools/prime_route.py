@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Lengths with a prime factor 17..61: LDS mixed-radix kernel (generic O(r^2) pass) against the one-launch chirp-z
-kernel (AETH_FFT_PRIME_BLU=1).  256 MiB operands, out of place; EVM against numpy's f64 transform."""
+"""Lengths with a prime factor 17..61, three routes side by side: the LDS mixed-radix kernel with the generic O(r^2)
+pass (AETH_MIXED_BIGR=0), the same kernel with its register butterflies for 11..23, and the route the library takes
+(one-launch chirp-z kernel, or the ragged table where the length has a row).  256 MiB operands, out of place; EVM
+against numpy's f64 transform."""
 import os, sys, statistics
 os.environ['AETH_TUNING'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
