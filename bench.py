@@ -442,6 +442,10 @@ def main():
         }
         if single is not None:
             line["single_queue"] = single
+            # the same kernel one dispatch at a time (what rocprofv3 --kernel-trace --stats averages): kept inside the
+            # roofline object too, so that nobody reads the step-level fraction as a per-dispatch one
+            line["roofline"]["per_dispatch_ms"] = single["kernel_ms"]
+            line["roofline"]["per_dispatch_frac"] = single["frac"]
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
