@@ -50,6 +50,10 @@ enum : int {
     V_DECIM = 512,  // product variant: decimating store (aeth_fir_exec_decim)
     V_UNROLL2 = 4096, // the block loop unrolled by two with the roles of the two window register sets swapped (no copy)
     V_XOR = 2048,   // XOR-swizzled LDS exchange image instead of the padded one (see aeth_fft_core.h: pidx)
+    V_XCD = 8192,   // lab only, measured negative (54.1 -> 55.5 us, two queues 48.5 -> 50.2): workgroups of one XCD
+                    // (blockIdx % 8) take ADJACENT blocks of a round, so that the 63-sample halo a block shares with
+                    // its neighbour is read through the same L2 -- round-robin over the XCDs spreads every region of
+                    // the stream over all eight L2s and wins
     V_DEMOD = 1024, // product variant: hard demodulation instead of the sample store (aeth_fft_mul_ifft_demod)
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
     V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
@@ -312,7 +316,11 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
     constexpr bool TOUCH = (VAR & V_TOUCH) && C::F == 1 && !BLU;
     constexpr int TOUCH_AHEAD = (VAR & V_TOUCH3) ? 3 : 2;
     cf nx[C::P], tw[C::TW], H[C::P];
-    long long g0 = blockIdx.x;
+    unsigned bid = blockIdx.x;
+    if constexpr ((VAR & V_XCD) != 0) {
+        if ((gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    }
+    long long g0 = bid;
     unsigned tprev = 0;     // V_TOUCH: the previous round's touch result, kept alive until the next round (never used)
 
     if constexpr (PEEL) {
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         // first pass needs window 0 only, so its wait leaves the tables and the next window in flight; they land
         // while pass 0 and the first exchange run.
         cf w[C::P];
-        if (blockIdx.x == 0) load_window<C, NT>(w, a, 0, tid);     // history / zero initial state: predicated path
+        if (bid == 0) load_window<C, NT>(w, a, 0, tid);     // history / zero initial state: predicated path
         else load_window_srd<C, NT>(w, a, g0, tid);
         if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
         else load_twiddles<C>(tw, a.twN, tid);
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
     } else {
         // software pipeline: the next block's window is in flight while this one is transformed.
         // The first window goes out before the (L2-resident) tables so the HBM fetch starts at once.
-        load_window<C, NT>(nx, a, (long long)blockIdx.x * C::F + fl, tid);
+        load_window<C, NT>(nx, a, (long long)bid * C::F + fl, tid);
         if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
         else load_twiddles<C>(tw, a.twN, tid);
 #pragma unroll
