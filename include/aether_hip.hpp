@@ -16,6 +16,7 @@
 #include <cmath>
 #include <complex>
 #include <cstddef>
+#include <cstdio>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -245,6 +246,22 @@ public:
     {
         y.resize(x.size());
         check(aeth_fir_exec_host(h_, nullptr, raw(x.data()), x.size(), raw(y.data())));
+    }
+    // host-resident stream through the upload | kernel | download pipeline (src/pipeline.rs counterpart); with report =
+    // true the reference pipeline's per-stage lines (pipeline.rs:101-108) go to stdout
+    aeth_pipe_util filter_stream(const std::vector<cf32> &x, std::vector<cf32> &y, size_t chunk = 0, bool report = false)
+    {
+        y.resize(x.size());
+        aeth_pipe_util u{};
+        check(aeth_fir_stream_host_util(h_, raw(x.data()), x.size(), raw(y.data()), chunk, &u));
+        if (report && u.seconds > 0) {
+            const char *names[3] = {"upload", "kernel", "download"};
+            const double act[3] = {u.active_upload, u.active_kernel, u.active_download};
+            for (int s = 0; s < 3; s++)
+                std::printf("Stage: %-15s : Processed %llu in %3.3fs (%9.2f/s); Utilisation: %3.2f%%\n", names[s],
+                            (unsigned long long)u.chunks, u.seconds, u.chunks / u.seconds, act[s] / u.seconds * 100.0);
+        }
+        return u;
     }
     // the filter followed by sampling::downsample (sampling.rs:28-42) in one pass: y[i] = fir(x)[i * (x.len / y.len)]
     void filter_decim(const DeviceVec &x, DeviceVec &y, const DeviceVec *hist = nullptr)

@@ -7,7 +7,7 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 #[repr(C)] pub struct aeth_fft { _p: [u8; 0] }
 #[repr(C)] pub struct aeth_fir { _p: [u8; 0] }
 #[repr(C)] pub struct aeth_event { _p: [u8; 0] }
-/// aeth_pipe_stats: what the double-buffered host-stream pipeline reports
+/// aeth_pipe_stats: what the three-stage host-stream pipeline reports
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct aeth_pipe_stats { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64 }
 /// aeth_pipe_util: the same plus the seconds each stage (upload, kernel, download) was active -- the per-stage

@@ -170,7 +170,7 @@ impl<'c> Fir<'c> {
         assert_eq!(x.n, y.n, "Vectors must have same length");
         check(unsafe { aeth_fir_exec(self.h, ptr::null(), x.p, x.n, y.p) });
     }
-    /// host-resident stream through the double-buffered H2D | kernel | D2H pipeline (src/pipeline.rs counterpart)
+    /// host-resident stream through the three-stage H2D | kernel | D2H pipeline (src/pipeline.rs counterpart)
     pub fn filter_stream(&mut self, x: &[cf32], y: &mut [cf32]) -> aeth_pipe_stats {
         assert_eq!(x.len(), y.len(), "Vectors must have same length");
         let mut st = aeth_pipe_stats::default();

@@ -121,6 +121,20 @@ int main()
         for (int k = 64; k < 5000; k++) if (std::abs(y[k]) > 1e-6f) throw Panic(0, "tail");
     });
 
+    // host-resident stream through the three-stage pipeline: the bits of the one-call flavour, and the stage report
+    RUN("fir stream pipeline with the per-stage report", {
+        std::vector<cf32> taps(64); for (int k = 0; k < 64; k++) taps[k] = cf32(1.0f / (k + 1), 0.01f * k);
+        const size_t n = 1984 * 700 + 17;
+        std::vector<cf32> x(n), y, z;
+        for (size_t i = 0; i < n; i++) x[i] = cf32(std::sin(0.01f * i), std::cos(0.013f * i));
+        Fir fir(ctx, taps, 2048);
+        fir.filter(x, y);
+        const aeth_pipe_util u = fir.filter_stream(x, z, 1984 * 100, true);
+        if (z.size() != n || std::memcmp(y.data(), z.data(), n * sizeof(cf32)) != 0) throw Panic(0, "stream != one call");
+        if (u.chunks != 8 || u.samples != (double)n || !(u.seconds > 0)) throw Panic(0, "stats");
+        if (!(u.active_upload > 0 && u.active_kernel > 0 && u.active_download > 0)) throw Panic(0, "stage times");
+    });
+
     // overlap lane + decimating store: consecutive independent launches on two queues give the bits of the plain run
     RUN("fir on the overlap lane, and with a decimating store", {
         std::vector<cf32> taps(64); for (int k = 0; k < 64; k++) taps[k] = cf32(1.0f / (k + 1), 0.01f * k);
