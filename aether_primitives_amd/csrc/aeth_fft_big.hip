@@ -519,7 +519,8 @@ int fft_plan_bluestein(aeth_fft *plan)
     // or above 2N-1 that one register-resident launch transforms (N = 4099: 8640 = 2^6 3^3 5 instead of 16384, half the
     // bytes through each of the five launches).
     if (M > 4096 && aeth::tuning_int("AETH_BLU_ANY_M", 1)) {
-        for (size_t m = 2 * N - 1; m < M; m++)
+        const size_t table_top = 20480;                    // the largest length the ragged table holds
+        for (size_t m = 2 * N - 1; m < M && m <= table_top; m++)
             if (aeth::fft_ragged_supported(m)) { M = m; break; }
     }
     plan->blu_m = M;
