@@ -191,7 +191,7 @@ __device__ __forceinline__ void demod_block(const cf (&w)[C::P], const FmiArgs &
                 float p0 = dr * dr, p1 = di * di;
                 asm volatile("" : "+v"(p0), "+v"(p1));
                 const float d = p0 + p1;
-                if (c == 0 || d < bd) { best = (unsigned)c; bd = d; }
+                if (c == 0 || !(bd <= d)) { best = (unsigned)c; bd = d; }     // min_by: aeth_modulation.hip, nearest()
             }
         }
         if (e >= a.ov && o < a.n && e < a.frame_n) {

@@ -29,6 +29,10 @@ __device__ __forceinline__ float2 pick(const Table4 &t, unsigned idx)
     return b1 ? hi : lo;
 }
 
+// nearest_rule: the reference folds the candidates with min_by(|d, e| d.partial_cmp(e).unwrap_or(Ordering::Greater))
+// (modulation.rs:46, :139).  min_by keeps the running minimum unless the comparison says Greater, so the minimum is
+// replaced by a strictly smaller distance AND by any unordered pair (a NaN on either side); of equal distances the
+// first stays.  `!(bd <= d)` is exactly that; a NaN sample decodes as the last candidate scanned.
 __device__ __forceinline__ unsigned nearest(float2 v, const Table4 &t, int ncand)
 {
     unsigned best = 0;
@@ -38,7 +42,7 @@ __device__ __forceinline__ unsigned nearest(float2 v, const Table4 &t, int ncand
         if (i >= ncand) break;
         const float dr = v.x - t.s[i].x, di = v.y - t.s[i].y;
         const float d = dr * dr + di * di;                                        // modulation.rs:36-41
-        if (i == 0 || d < bd) { best = (unsigned)i; bd = d; }                     // first minimum wins (:46-49)
+        if (i == 0 || !(bd <= d)) { best = (unsigned)i; bd = d; }                 // min_by (:46-49): see nearest_rule below
     }
     return best;
 }
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void demod_generic_kernel(const float2 *__r
     for (int c = 0; c < ncand; c++) {
         const float dr = v.x - tab[c].x, di = v.y - tab[c].y;                                   // :136
         const float d = dr * dr + di * di;                                                      // :137
-        if (c == 0 || d < bd) { best = (unsigned)c; bd = d; }                                   // first minimum (:139)
+        if (c == 0 || !(bd <= d)) { best = (unsigned)c; bd = d; }                               // min_by (:139), same rule
     }
     for (int k = 0; k < bps; k++) bits[i * (size_t)bps + k] = (uint8_t)((best >> k) & 1u);      // :143
 }

@@ -283,8 +283,10 @@ AETH_API int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits_dev, size_t nbits,
 AETH_API int aeth_modulate_awgn(aeth_ctx *ctx, const uint8_t *bits_dev, size_t nbits, int bits_per_symbol,
                                 const aeth_cf32 *table_host, aeth_cf32 *out_dev, size_t n_out, float power,
                                 uint64_t seed, uint64_t offset);
-/* Modulation::demod_naive: nearest table symbol by squared distance, the FIRST minimum wins
- * (min_by keeps the first of equals).  compat != 0 reproduces the QPSK specialisation's
+/* Modulation::demod_naive: nearest table symbol by squared distance, folded exactly as the reference's
+ * min_by(|d, e| d.partial_cmp(e).unwrap_or(Ordering::Greater)) (:46, :139): of equal distances the FIRST stays, a
+ * strictly smaller one replaces it, and so does an unordered pair -- a sample with a NaN component decodes as the
+ * last candidate scanned.  compat != 0 reproduces the QPSK specialisation's
  * output exactly (:33-56): it pushes `idx & 1` and `idx & 1u8 << 1` == idx & 2, i.e. the
  * second bit comes out as 0 or 2; compat == 0 emits (idx >> 1) & 1.  BPSK follows the
  * trait default (:133-144).  bits_out_dev receives nsym * bits_per_symbol bytes. */

@@ -475,8 +475,8 @@ void orc_qpsk_modulate(const uint8_t *bits, size_t nbits, orc_cf32 *out)
     }
 }
 
-/* demod_naive for [cf32;4] :33-56: min squared distance, first minimum wins
- * (min_by keeps the first of equal elements); emits idx & 1 and
+/* demod_naive for [cf32;4] :33-56: min squared distance by min_by (of equal elements the first
+ * stays; an unordered pair replaces the running minimum -- see orc_demod_generic); emits idx & 1 and
  * `idx & 1u8 << 1` == idx & 2 (value 0 or 2 -- precedence quirk, :54) */
 void orc_qpsk_demod_naive(const orc_cf32 *sym, size_t nsym, uint8_t *bits_out)
 {
@@ -485,7 +485,7 @@ void orc_qpsk_demod_naive(const orc_cf32 *sym, size_t nsym, uint8_t *bits_out)
         for (int i = 0; i < 4; i++) {
             float dr = sym[s].re - QPSK[i].re, di = sym[s].im - QPSK[i].im;
             float d = dr * dr + di * di;
-            if (i == 0 || d < bd) { best = i; bd = d; }
+            if (i == 0 || !(bd <= d)) { best = i; bd = d; }      /* min_by: see orc_demod_generic */
         }
         bits_out[2 * s] = (uint8_t)(best & 1);
         bits_out[2 * s + 1] = (uint8_t)(best & 2);
@@ -517,7 +517,10 @@ static int orc_demod_generic(const orc_cf32 *sym, size_t nsym, int bps, const or
         for (int i = 0; i < ncand; i++) {
             float dr = sym[s].re - table[i].re, di = sym[s].im - table[i].im;                   /* :136 */
             float d = dr * dr + di * di;                                                        /* :137 */
-            if (i == 0 || d < bd) { best = i; bd = d; }                                         /* :139 first minimum */
+            /* :139-140 min_by(|d, e| d.partial_cmp(e).unwrap_or(Greater)): the running minimum is replaced when the comparison
+             * says Greater -- a strictly smaller distance, or an unordered pair (NaN on either side); of equal
+             * distances the first stays.  A NaN sample therefore decodes as the LAST candidate. */
+            if (i == 0 || !(bd <= d)) { best = i; bd = d; }
         }
         for (int i = 0; i < bps; i++) bits_out[s * (size_t)bps + i] = (uint8_t)((best >> i) & 1);   /* :143 */
     }
@@ -549,7 +552,7 @@ int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *t
         for (int i = 0; i < ncand; i++) {
             float dr = sym[s].re - t[i].re, di = sym[s].im - t[i].im;
             float d = dr * dr + di * di;
-            if (i == 0 || d < bd) { best = i; bd = d; }
+            if (i == 0 || !(bd <= d)) { best = i; bd = d; }      /* min_by: see orc_demod_generic */
         }
         if (bps == 1) bits_out[s] = (uint8_t)(best & 1);                             /* :143 */
         else {

@@ -47,6 +47,31 @@ def test_demod_quirk_and_ties(ctx, oracle):
         q.modulate(np.array([0, 1, 1], np.uint8))               # not a multiple of BITS_PER_SYMBOL
 
 
+def test_demod_unordered_distances_follow_min_by(ctx, oracle):
+    """min_by(|d, e| d.partial_cmp(e).unwrap_or(Ordering::Greater)) (modulation.rs:46, :139) replaces the running
+    minimum whenever the comparison says Greater: on a strictly smaller distance and on an unordered pair.  A sample
+    with a NaN component makes every distance NaN, so it decodes as the LAST candidate scanned (QPSK: index 3, BPSK:
+    index 1); equal infinite distances keep the first."""
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    sym = np.array([complex(nan, 0.3), complex(-0.2, nan), complex(nan, nan), complex(inf, inf), complex(-inf, 0.0),
+                    0.7 + 0.7j, complex(0.1, -0.9)], np.complex64)
+    q = modulation.qpsk(ctx)
+    got = q.demod_naive(ctx.vec(sym), compat=False).to_host().reshape(-1, 2)
+    assert got[:3].tolist() == [[1, 1]] * 3                     # index 3
+    assert got[3].tolist() == [0, 0] and got[4].tolist() == [0, 0]   # all distances +inf: Equal, the first stays
+    assert got[5].tolist() == [0, 0] and got[6].tolist() == [0, 1]
+    assert (q.demod_naive(ctx.vec(sym)).to_host() == oracle.demod_naive(sym, 2)).all()
+    b = modulation.bpsk(ctx)
+    assert b.demod_naive(ctx.vec(sym)).to_host().tolist()[:5] == [1, 1, 1, 0, 0]
+    assert (b.demod_naive(ctx.vec(sym)).to_host() == oracle.demod_naive(sym, 1)).all()
+    # a generic 3-bit table: the trait default scans BITS_PER_SYMBOL * 2 = 6 candidates, a NaN sample takes the sixth
+    tab = np.exp(2j * np.pi * np.arange(8) / 8).astype(np.complex64)
+    g = modulation.table(ctx, tab)
+    want = oracle.demod_naive(sym, 3, table=tab)
+    assert (g.demod_naive(ctx.vec(sym)).to_host() == want).all()
+    assert want[:3].tolist() == [1, 0, 1]                       # index 5 = 0b101, least significant bit first
+
+
 @pytest.mark.parametrize("n,offset", [(1, 0), (2, 0), (7, 0), (7, 3), (4096, 0), (100001, 5), (1 << 20, 1 << 33)])
 def test_awgn_apply_bit_exact(ctx, oracle, n, offset):
     """Awgn::apply (noise.rs:53-59) around the build's counter-based generator: bit for bit

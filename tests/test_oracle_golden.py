@@ -151,6 +151,18 @@ def test_assert_evm_kat(oracle, cid):
             ap.assert_evm(expand(c["act"]), expand(c["ref"]), c["evm_db"])
 
 
+def test_demod_min_by_rule_on_unordered_distances(oracle):
+    """modulation.rs:46 / :139: min_by with partial_cmp(..).unwrap_or(Greater) -- Greater (a smaller distance OR an
+    unordered pair) replaces the running minimum, Less / Equal keep it.  NaN sample -> last candidate; ties -> first."""
+    nan = np.float32(np.nan)
+    sym = np.array([complex(nan, 0.0), complex(1.0, nan), 0j, 1 + 1j, -1 - 1j], np.complex64)
+    q = oracle.demod_naive(sym, 2).reshape(-1, 2)
+    assert q[0].tolist() == [1, 2] and q[1].tolist() == [1, 2]          # index 3, with the `idx & 1u8 << 1` quirk
+    assert q[2].tolist() == [0, 0] and q[3].tolist() == [0, 0] and q[4].tolist() == [1, 2]
+    b = oracle.demod_naive(sym, 1)
+    assert b.tolist() == [1, 1, 0, 0, 1]
+
+
 def test_assert_evm_rejects_nan_and_bad_args(oracle):
     r = np.ones(2, np.complex64)
     a = r.copy(); a[1] = np.nan
