@@ -275,6 +275,7 @@ int aeth_fir_exec_decim(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in,
     AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
     if (n == 0 && n_out == 0) return AETH_OK;
     AETH_REQUIRE(n_out > 0 && n % n_out == 0, AETH_E_ARG, AETH_MSG_DECIM);          /* sampling.rs:32-36 */
+    AETH_REQUIRE(n >= n_out, AETH_E_LEN, "downsample from an empty src (the reference panics: index out of bounds)");
     const size_t dec = n / n_out;
     if (dec == 1) return aeth_fir_exec(f, hist, in, n, out);
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");

@@ -200,6 +200,8 @@ int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, siz
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
     AETH_REQUIRE(n_dst > 0, AETH_E_LEN, "downsample into an empty dst (division by zero in the reference)");
     AETH_REQUIRE(n_src % n_dst == 0, AETH_E_LEN, AETH_MSG_DECIM);
+    /* 0 % n == 0 passes the reference's assert too; dec = 0 then reads src[0] of an empty slice and panics (:39-41) */
+    AETH_REQUIRE(n_src >= n_dst, AETH_E_LEN, "downsample from an empty src (the reference panics: index out of bounds)");
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(elem == 1 || elem == 2 || elem == 4 || elem == 8 || elem == 16, AETH_E_ARG,
                  "elem_size %zu not in {1,2,4,8,16}", elem);
@@ -231,6 +233,8 @@ int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
     AETH_REQUIRE(n_dst > 0, AETH_E_LEN, "downsample into an empty dst (division by zero in the reference)");
     AETH_REQUIRE(n_src % n_dst == 0, AETH_E_LEN, AETH_MSG_DECIM);
+    /* 0 % n == 0 passes the reference's assert too; dec = 0 then reads src[0] of an empty slice and panics (:39-41) */
+    AETH_REQUIRE(n_src >= n_dst, AETH_E_LEN, "downsample from an empty src (the reference panics: index out of bounds)");
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
     int rc = aeth::ctx_stage(ctx, 0, n_src * elem); if (rc) return rc;
     rc = aeth::ctx_stage(ctx, 1, n_dst * elem); if (rc) return rc;

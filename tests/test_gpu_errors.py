@@ -46,6 +46,11 @@ def test_bad_arguments(ctx):
     assert lib.aeth_vec_scale(ctx.h, C.c_void_p(v.ptr + 4), 1, 1.0) == _lib.E_ALIGN
     assert b"aligned" in lib.aeth_last_error()
     assert lib.aeth_downsample(ctx.h, v._p(), 64, v._p(), 8, 3) == _lib.E_ARG           # elem_size 3
+    # 0 % n == 0 passes the reference's divisibility assert; dec = 0 then indexes an empty slice and panics (sampling.rs:39-41)
+    assert lib.aeth_downsample(ctx.h, v._p(), 0, v._p(), 8, 8) == _lib.E_LEN
+    assert b"empty src" in lib.aeth_last_error()
+    fd = Fir(ctx, np.ones(8, np.complex64), 2048)
+    assert lib.aeth_fir_exec_decim(fd.h, None, v._p(), 0, v._p(), 4) == _lib.E_LEN
     assert lib.aeth_modulate(ctx.h, v._p(), 4, 3, None, v._p(), 1) == _lib.E_ARG          # 3 bits per symbol: needs a table
     assert lib.aeth_modulate(ctx.h, v._p(), 9, 9, v._p(), v._p(), 1) == _lib.E_UNSUPPORTED  # 9 bits per symbol
     with pytest.raises(ap.AetherError):
