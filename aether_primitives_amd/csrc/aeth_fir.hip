@@ -341,6 +341,7 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
     aeth::DeviceGuard g(ctx->device);
     const size_t nh = f->ntaps - 1;
     if (chunk == 0) chunk = (size_t)4 << 20;                       // 32 MiB of samples per transfer
+    if (chunk > n) chunk = n;                                      // a short stream: slots no larger than it needs
     chunk = ((chunk + f->hop - 1) / f->hop) * f->hop;              // hop-aligned: same blocks as the one-shot run
     const size_t nchunks = (n + chunk - 1) / chunk;
     // pin the caller's slices in place for true asynchronous copies (falls back to pageable copies)
