@@ -396,6 +396,8 @@ template <int P, int S> struct BflyOddPrime {
 template <int S> struct Bfly<11, S> : BflyOddPrime<11, S> {};
 template <int S> struct Bfly<13, S> : BflyOddPrime<13, S> {};
 template <int S> struct Bfly<17, S> : BflyOddPrime<17, S> {};
+template <int S> struct Bfly<19, S> : BflyOddPrime<19, S> {};
+template <int S> struct Bfly<23, S> : BflyOddPrime<23, S> {};
 
 // R = R1*R2:  X[k1 + R1*k2] = sum_n2 W_R2^(n2 k2) [ W_R^(n2 k1) sum_n1 x[n1*R2 + n2] W_R1^(n1 k1) ]
 // the inner twiddles W_R^(n2 k1) are compile-time constants held in SGPR pairs

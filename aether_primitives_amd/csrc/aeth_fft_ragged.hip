@@ -1,6 +1,6 @@
 // aeth_fft_ragged.hip -- the "stockham_mixed_ragged" path of trait Fft (reference src/fft.rs:48-77): every length
-// 2^a 3^b 5^c from 3 to 20480 that is no power of two, 16384, lengths with a factor 7 up to 4096 and with a factor 11,
-// 13 or 17 up to 2048 -- one measured decomposition each (aeth_fft_ragged.h has the kernel, aeth_fft_ragged_table.inc
+// 2^a 3^b 5^c from 3 to 20480 that is no power of two, 8192, 16384, lengths with a factor 7 up to 4096 and with a
+// factor 11, 13, 17, 19 or 23 up to 2048 -- one measured decomposition each (aeth_fft_ragged.h has the kernel, aeth_fft_ragged_table.inc
 // the table).  The table is compiled in four slices -- this file once per slice with -DAETH_RAGGED_PART=k -- so
 // that the build spreads over the cores.
 #include "aeth_fft_ragged.h"

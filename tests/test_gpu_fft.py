@@ -20,6 +20,17 @@ KAT = load_kat()
 TOL_DB = -120.0
 
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
+
+
+def _largest_prime_factor(n):
+    best, f = 1, 2
+    while f * f <= n:
+        while n % f == 0:
+            best, n = f, n // f
+        f += 1
+    return n if n > 1 else best
+
+
 # the ragged register-resident table: every length 2^a 3^b 5^c up to 20480 that is no power of two, 8192, 16384, and every
 # length 2^a 3^b 5^c 7^d up to 4096 with d >= 1
 SMOOTH = sorted(({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10) for c in range(7)
@@ -33,7 +44,10 @@ SMOOTH = sorted(({2 ** a * 3 ** b * 5 ** c for a in range(15) for b in range(10)
                 # ... and every 17-smooth length up to 2048 with a factor 17 that has a decomposition of at most 34 points per lane
                 | ({17 ** g * m for g in (1, 2) for m in range(1, 121)
                     if 17 ** g * m <= 2048 and all(m % q for q in (19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113))}
-                   - {578, 748}))
+                   - {578, 748})
+                # ... and the 23-smooth lengths up to 2048 whose largest prime factor is 19 or 23 (15 of the 143 have no row)
+                | ({n for n in range(19, 2049) if _largest_prime_factor(n) in (19, 23)}
+                   - {418, 437, 506, 529, 646, 665, 722, 759, 782, 828, 836, 874, 897, 1012, 1058}))
 MIXED = [1, 17, 19, 34, 61, 289, 323, 2079, 4095, 4116, 7203, 8190,           # LDS ping-pong kernel
          # ... with its register butterflies for 11 .. 23 (beyond the one-launch chirp-z kernel's 2048), alone and mixed
          # with a radix that still takes the O(r^2) pass (37)
@@ -146,7 +160,8 @@ def test_algorithms_chosen(ctx):
     assert HipFft(ctx, 143).algorithm == "stockham_mixed_ragged"
     assert HipFft(ctx, 1700).algorithm == "stockham_mixed_ragged"      # 4 * 25 * 17: radix 17 in registers
     assert HipFft(ctx, 578).algorithm == "bluestein"                   # 2 * 17^2: no register decomposition in the table
-    assert HipFft(ctx, 323).algorithm == "bluestein"                 # 17 * 19: one-launch chirp-z beats the O(r^2) prime pass
+    assert HipFft(ctx, 323).algorithm == "stockham_mixed_ragged"     # 17 * 19: radix 17 and 19 in registers
+    assert HipFft(ctx, 437).algorithm == "bluestein"                 # 19 * 23: no row; one-launch chirp-z beats the O(r^2) prime pass
     assert HipFft(ctx, 2 * 2057).algorithm == "stockham_mixed"       # 4114 = 2 * 11^2 * 17: too long for the one-launch kernel
     assert HipFft(ctx, 65536).algorithm == "fourstep_pow2"
     assert HipFft(ctx, 4099).algorithm == "bluestein"

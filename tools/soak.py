@@ -22,7 +22,14 @@ eleven = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f for a in 
                  if e + f >= 1 and 2 ** a * 3 ** b * 5 ** c * 7 ** d * 11 ** e * 13 ** f <= 2048})
 seventeen = sorted({17 ** g * m for g in (1, 2) for m in range(1, 121) if 17 ** g * m <= 2048
                     and all(m % q for q in (19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113))})
-lengths = [2 ** k for k in range(1, 17)] + smooth + seven + eleven + seventeen + [
+def _lpf(n):
+    best, f = 1, 2
+    while f * f <= n:
+        while n % f == 0: best, n = f, n // f
+        f += 1
+    return n if n > 1 else best
+nineteen = [n for n in range(19, 2049) if _lpf(n) in (19, 23)]
+lengths = [2 ** k for k in range(1, 17)] + smooth + seven + eleven + seventeen + nineteen + [
     17, 19, 34, 67, 127, 134, 323, 257, 509, 1009, 2039, 4099, 4116, 7203, 8190, 9604, 23040, 30720, 100000,
     # round 2: register butterflies 11 .. 23 in the LDS kernel, chirp-z with a free convolution length, four-step splits
     2176, 2431, 3553, 4199, 6647, 6859, 7429, 8177, 4583, 5003, 6007, 8191, 10007, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21]
