@@ -634,11 +634,17 @@ bool factorize_mixed(size_t n, std::vector<int> &fac)
 bool split_fourstep_mixed(size_t len, size_t *n1, size_t *n2)
 {
     auto fast = [](size_t n) { return (is_pow2(n) && n <= 8192) || aeth::fft_ragged_supported(n); };
-    // a small first factor over one register-resident transform (up to 20480 points): no transposes
-    for (size_t r = 2; r <= 16; r++) {
-        if (!aeth::fourstep_small_factor(r) || len % r) continue;
-        if (fast(len / r)) { *n1 = r; *n2 = len / r; return true; }
-    }
+    // a small first factor over one register-resident transform (up to 20480 points): no transposes.  The batched
+    // transform is the bulk of the three launches and the rows from 8192 points down run at 4.3-5.9 TB/s where the
+    // largest ones reach 2.9-4.1, so the smallest factor that brings the rest under that length goes first
+    // (40960 as 5 x 8192 instead of 2 x 20480)
+    const size_t pref = (size_t)aeth::tuning_int("AETH_4SM_PREF_M", 8192);
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t r = 2; r <= 16; r++) {
+            if (!aeth::fourstep_small_factor(r) || len % r) continue;
+            if (pass == 0 && len / r > pref) continue;
+            if (fast(len / r)) { *n1 = r; *n2 = len / r; return true; }
+        }
     size_t root = 1;
     while ((root + 1) * (root + 1) <= len) root++;
     size_t fb1 = 0, fb2 = 0;
