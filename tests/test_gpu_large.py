@@ -181,3 +181,12 @@ def test_fourstep_largest_lengths(ctx, oracle, logn):
     assert bits_equal(o.to_host(), d.to_host())
     back = ctx.vec(d.to_host()); f.ibwd(back, Scale.SN)
     assert oracle.evm_db(back.to_host(), x) <= -120
+    if logn == 23:
+        # a batch of frames through the deep form (columns over all frames, nested rows, transpose per frame): every
+        # frame comes out with the bits of the single-frame run
+        y = rand_c64(99, n)
+        two = ctx.vec(np.concatenate([x, y])); f.fwd(two, two, Scale.SN)
+        got = two.to_host()
+        assert bits_equal(got[:n], d.to_host())
+        e = ctx.vec(y); f.ifwd(e, Scale.SN)
+        assert bits_equal(got[n:], e.to_host())
