@@ -40,6 +40,12 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     long long ngroups = (a.nblocks + C::F - 1) / C::F;
     // persistent grid = what is resident at once: the kernel's ~230 VGPRs allow 2 waves per SIMD, 8 per CU
     long long cap = (long long)ctx->num_cus * 8 / (C::WG / 64);
+    // Tuning only (AETH_FIR_OVERLAP_GRID=1), measured and not the default: with the overlap lane on, three of the four
+    // 128-lane workgroups a CU holds, so that the next launch runs beside this one from the start instead of only
+    // under its tail.  tools/fir_lab, two queues, 300-step chains, grids 704 ... 800 of 1024: 46.6 us per launch
+    // against 47.5 -- but through the library a 200-launch chain gains 0.4 % and a 20-launch region LOSES 1.3 % (its
+    // first and last launches run alone, where the smaller grid costs 54.4 us against 53.5).
+    if (ctx->overlap && C::WG == 128 && aeth::tuning_int("AETH_FIR_OVERLAP_GRID", 0)) cap = cap * 3 / 4;
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
     FmiArgs b = a;

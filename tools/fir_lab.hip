@@ -119,6 +119,9 @@ int main(int argc, char **argv)
         {"xor+prio+unroll2", 6148, 0, 0}, {"xor+prio+unroll2/2q", 6148, 2, 0},
         {"xor", 2048, 0, 0}, {"xor+prio", 2052, 0, 0}, {"xor+prio/2q", 2052, 2, 0}, {"xor+nomem", 2096, 0, 0},
         {"xor+prio+xcd", 10244, 0, 0}, {"xor+prio+xcd/2q", 10244, 2, 0},
+        {"xor+prio/g768/2q", 2052, 2, 768}, {"xor+prio/g896/2q", 2052, 2, 896}, {"xor+prio/g768", 2052, 0, 768},
+        {"xor+prio/g704/2q", 2052, 2, 704}, {"xor+prio/g736/2q", 2052, 2, 736}, {"xor+prio/g800/2q", 2052, 2, 800},
+        {"xor+prio/g832/2q", 2052, 2, 832}, {"xor+prio/g960/2q", 2052, 2, 960},
         {"nolds/2q", 128, 2, 0}, {"prio/2q", 4, 2, 0}, {"peel/2q", 1, 2, 0},
         {"nomem", 48, 0, 0}, {"nomem/g768", 48, 0, 768}, {"nomem/g512", 48, 0, 512}, {"nomem/g256", 48, 0, 256},
     };
