@@ -40,12 +40,17 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     long long ngroups = (a.nblocks + C::F - 1) / C::F;
     // persistent grid = what is resident at once: the kernel's ~230 VGPRs allow 2 waves per SIMD, 8 per CU
     long long cap = (long long)ctx->num_cus * 8 / (C::WG / 64);
-    // Tuning only (AETH_FIR_OVERLAP_GRID=1), measured and not the default: with the overlap lane on, three of the four
-    // 128-lane workgroups a CU holds, so that the next launch runs beside this one from the start instead of only
-    // under its tail.  tools/fir_lab, two queues, 300-step chains, grids 704 ... 800 of 1024: 46.6 us per launch
-    // against 47.5 -- but through the library a 200-launch chain gains 0.4 % and a 20-launch region LOSES 1.3 % (its
-    // first and last launches run alone, where the smaller grid costs 54.4 us against 53.5).
-    if (ctx->overlap && C::WG == 128 && aeth::tuning_int("AETH_FIR_OVERLAP_GRID", 0)) cap = cap * 3 / 4;
+    // A launch that runs BESIDE its predecessor on the overlap lane takes three of the four 128-lane workgroups a CU
+    // holds: a full grid keeps every wave slot until its last round, so its successor could only overlap that tail;
+    // with a slot per CU free the two run side by side from the start.  tools/fir_lab, two queues, grids 704 ... 800
+    // of 1024: 46.6 us per launch against 47.5; through the library, alternating in one process
+    // (tools/overlap_grid_ab.py, 25 rounds): regions of 20 launches -1.8 %, of 200 launches -1.4 %.  A launch on its own
+    // (one queue, or the first of a chain) keeps the full grid: 53.5 us against 54.4.
+    // AETH_FIR_OVERLAP_GRID: 0 = always the full grid, 1 = three quarters whenever the lane is on, 2 = as described.
+    if (ctx->overlap && C::WG == 128) {
+        const int og = aeth::tuning_int("AETH_FIR_OVERLAP_GRID", 2);
+        if (og == 1 || (og == 2 && ctx->last_chained)) cap = cap * 3 / 4;
+    }
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
     FmiArgs b = a;
@@ -351,8 +356,12 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
     chunk = ((chunk + f->hop - 1) / f->hop) * f->hop;              // hop-aligned: same blocks as the one-shot run
     const size_t nchunks = (n + chunk - 1) / chunk;
     // pin the caller's slices in place for true asynchronous copies (falls back to pageable copies)
-    const bool pin_in = hipHostRegister(const_cast<aeth_cf32 *>(in), n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
-    const bool pin_out = hipHostRegister(out, n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
+    // (only streams of 16 MiB and more: below that the copies take microseconds either way, and registering and
+    // unregistering short-lived caller buffers by the thousand is not something the runtime's own pinned-range cache
+    // for pageable copies needs to be mixed with; without pinning the pipeline runs at 1.5-2 GS/s instead of 5.7)
+    const bool want_pin = aeth::tuning_int("AETH_PIPE_PIN", 1) != 0 && n * sizeof(float2) >= ((size_t)16 << 20);
+    const bool pin_in = want_pin && hipHostRegister(const_cast<aeth_cf32 *>(in), n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
+    const bool pin_out = want_pin && hipHostRegister(out, n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
     PipeSlot slot[kPipeSlots];
     hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;

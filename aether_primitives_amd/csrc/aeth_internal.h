@@ -26,6 +26,7 @@ struct aeth_ctx {
     bool overlap = false;          // feature switch (off for borrowed streams)
     bool aux_pending = false;      // the aux lane holds work the main stream is not yet ordered behind
     int chain_last = -1;           // lane of the latest FIR launch while nothing else has been enqueued since; else -1
+    bool last_chained = false;     // the latest ctx_fir_lane call put its launch beside its predecessor
     uintptr_t last_in[2] = {0, 0}, last_out[2] = {0, 0};   // [lo, hi) byte ranges of that launch
     // device scratch of the host-slice flavours, grown on demand
     void *stage[2] = {nullptr, nullptr};

@@ -84,6 +84,7 @@ hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintpt
         return s;
     }
     if (lane == 1) ctx->aux_pending = true;
+    ctx->last_chained = chained;
     ctx->chain_last = lane;
     ctx->last_in[0] = in_lo; ctx->last_in[1] = in_hi;
     ctx->last_out[0] = out_lo; ctx->last_out[1] = out_hi;
