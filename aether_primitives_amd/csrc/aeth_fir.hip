@@ -369,9 +369,9 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
     auto fail = [&](hipError_t e, const char *what) { rc = aeth::hip_fail(e, what); };
     auto ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) { fail(e, what); return false; } return true; };
     const int nslots = (int)(nchunks < (size_t)kPipeSlots ? nchunks : (size_t)kPipeSlots);
-    if (ok(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate") &&
-        ok(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking), "hipStreamCreate"))
-        (void)ok(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking), "hipStreamCreate");
+    for (int i = 0; i < 3 && rc == AETH_OK; i++)
+        if (!ctx->pipe_stream[i]) (void)ok(hipStreamCreateWithFlags(&ctx->pipe_stream[i], hipStreamNonBlocking), "hipStreamCreate");
+    s_up = ctx->pipe_stream[0]; s_run = ctx->pipe_stream[1]; s_down = ctx->pipe_stream[2];    // the context's, kept
     for (int s = 0; s < nslots && rc == AETH_OK; s++) {
         PipeSlot &sl = slot[s];
         if (!ok(hipEventCreateWithFlags(&sl.up, hipEventDisableTiming), "hipEventCreate")) break;
@@ -450,9 +450,6 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
         if (slot[s].ran) (void)hipEventDestroy(slot[s].ran);
         if (slot[s].down) (void)hipEventDestroy(slot[s].down);
     }
-    if (s_up) (void)hipStreamDestroy(s_up);
-    if (s_run) (void)hipStreamDestroy(s_run);
-    if (s_down) (void)hipStreamDestroy(s_down);
     if (t0) (void)hipEventDestroy(t0);
     if (t1) (void)hipEventDestroy(t1);
     if (pin_in) (void)hipHostUnregister(const_cast<aeth_cf32 *>(in));

@@ -28,6 +28,9 @@ struct aeth_ctx {
     int chain_last = -1;           // lane of the latest FIR launch while nothing else has been enqueued since; else -1
     bool last_chained = false;     // the latest ctx_fir_lane call put its launch beside its predecessor
     uintptr_t last_in[2] = {0, 0}, last_out[2] = {0, 0};   // [lo, hi) byte ranges of that launch
+    // the three stage streams of the host pipeline (aeth_fir_stream_host), created on its first run and kept: a
+    // stream per stage per call would create and destroy three HIP streams for every stream filtered
+    hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};
     // device scratch of the host-slice flavours, grown on demand
     void *stage[2] = {nullptr, nullptr};
     size_t stage_bytes[2] = {0, 0};

@@ -194,6 +194,8 @@ int aeth_ctx_destroy(aeth_ctx *ctx)
     aeth::DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(aeth::ctx_stream(ctx));
     overlap_release(ctx);
+    for (int i = 0; i < 3; i++)
+        if (ctx->pipe_stream[i]) { (void)hipStreamSynchronize(ctx->pipe_stream[i]); (void)hipStreamDestroy(ctx->pipe_stream[i]); }
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     }
