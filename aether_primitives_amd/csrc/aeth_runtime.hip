@@ -48,6 +48,7 @@ hipStream_t ctx_stream(aeth_ctx *ctx)
         ctx->aux_pending = false;
     }
     ctx->chain_last = -1;
+    ctx->last_chained = false;
     return ctx->stream_main;
 }
 
