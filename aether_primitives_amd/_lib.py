@@ -83,6 +83,17 @@ PROTOTYPES = {
     "aeth_fir_exec": (i32, [vp, vp, vp, sz, vp]),
     "aeth_fir_exec_decim": (i32, [vp, vp, vp, sz, vp, sz]),
     "aeth_fir_exec_host": (i32, [vp, vp, vp, sz, vp]),
+    "aeth_pool_create": (i32, [vp, sz, sz, i32, pvp]),
+    "aeth_pool_destroy": (i32, [vp]),
+    "aeth_pool_take": (i32, [vp, pvp]),
+    "aeth_pool_take_or_make": (i32, [vp, pvp]),
+    "aeth_pool_give_back": (i32, [vp, vp]),
+    "aeth_pool_len": (sz, [vp]),
+    "aeth_pool_cap": (sz, [vp]),
+    "aeth_pool_elem_bytes": (sz, [vp]),
+    "aeth_host_register": (i32, [vp, vp, sz]),
+    "aeth_host_unregister": (i32, [vp, vp]),
+    "aeth_host_is_pinned": (i32, [vp, sz]),
     "aeth_fir_stream_host": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_fir_stream_host_util": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_fir_stream_file": (i32, [vp, C.c_char_p, C.c_char_p, sz, vp]),
@@ -94,6 +105,8 @@ PROTOTYPES = {
     "aeth_host_interpolate": (i32, [vp, vp, sz, vp, sz, sz, i32, psz]),
     "aeth_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
     "aeth_host_downsample": (i32, [vp, vp, sz, vp, sz, sz]),
+    "aeth_downsample_release": (i32, [vp, vp, sz, vp, sz, sz, i32]),
+    "aeth_host_downsample_release": (i32, [vp, vp, sz, vp, sz, sz, i32]),
     "aeth_modulate": (i32, [vp, vp, sz, i32, vp, vp, sz]),
     "aeth_modulate_awgn": (i32, [vp, vp, sz, i32, vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
     "aeth_demod_naive": (i32, [vp, vp, sz, i32, vp, vp, sz, i32]),

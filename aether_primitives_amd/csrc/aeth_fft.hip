@@ -18,8 +18,9 @@
 //                   vecops.rs:443-463 at N=100), generic O(r^2) for other primes.
 //   fourstep_mixed  N > 8192 = n1 * n2 with both factors <= 8192: three transposes around
 //                   the batched transforms of the factors (aeth_fft_big.hip).
-//   fourstep_pow2   N = 2^13..2^23 (2^24: fourstep_mixed): N1 x N2 decomposition, two launches through the
-//                   plan's scratch (BASELINE config 5, N = 65536 = 256 x 256).
+//   fourstep_pow2   N = 2^14..2^24: N1 x N2 decomposition, two launches through the plan's scratch (BASELINE
+//                   config 5, N = 65536 = 256 x 256); 2^23 and 2^24 in the deep form (columns, nested four-step
+//                   rows, transpose: four launches, twice the scratch) -- aeth_fft_big.hip.
 //   bluestein       everything else: chirp-z through a power-of-two convolution.
 #include "aeth_internal.h"
 #include "aeth_fft_core.h"
@@ -705,6 +706,9 @@ namespace aeth {
 int fft_ensure_tmp(aeth_fft *plan, size_t elems)
 {
     if (plan->tmp_elems >= elems) return AETH_OK;
+    // the plan's device, whatever the caller's current one is: every caller (tfwd/tbwd, correlate + demod, the host
+    // flavours) allocates through here, and a temp on the wrong device is a fault in the kernels that follow
+    aeth::DeviceGuard dev_guard(plan->ctx->device);
     if (plan->tmp_dev) {
         AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(plan->ctx)));
         AETH_HIP(hipFree(plan->tmp_dev));

@@ -1,6 +1,9 @@
 // aeth_fft_big.hip -- transforms that do not fit one workgroup's LDS.
 //
-// fourstep_pow2 (N = 2^13 .. 2^23, BASELINE config 5 uses 65536 = 256 x 256):
+// fourstep_pow2 (N = 2^14 .. 2^24; 8192 and 16384 run in one workgroup, aeth_fft_ragged.hip; BASELINE config 5 uses
+// 65536 = 256 x 256; 2^23 and 2^24 take the DEEP form -- 128 / 256 columns over rows of 65536 points that are
+// four-step transforms of their own, then a tile transpose: four launches, and the sub-plan keeps a second
+// full-size work buffer, i.e. 2 x 8 B/sample of scratch, 256 MiB for one 2^24-point frame):
 //   x[n1*N2 + n2]  --A-->  a[k1*N2 + n2] = W_N^(n2*k1) * sum_n1 x[n1*N2+n2] W_N1^(n1*k1)
 //                  --B-->  X[k1 + N1*k2] = sum_n2 a[k1*N2+n2] W_N2^(n2*k2)
 //   A: a workgroup owns G adjacent columns (G*8 B contiguous per row: 128 B for G=16),
@@ -193,6 +196,7 @@ int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale, size_t b
 int ensure_work(aeth_fft *plan, size_t elems)
 {
     if (plan->work_elems >= elems) return AETH_OK;
+    aeth::DeviceGuard dev_guard(plan->ctx->device);        // the plan's device, not the caller's current one
     if (plan->work_dev) {
         AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(plan->ctx)));
         AETH_HIP(hipFree(plan->work_dev));

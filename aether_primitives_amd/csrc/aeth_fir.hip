@@ -22,6 +22,7 @@
 #include "aeth_fft_core.h"
 #include "aeth_fft_plan.h"
 #include "aeth_fir_kernel.h"
+#include "aeth_host.h"
 
 #include <cstdlib>
 #include <new>
@@ -46,10 +47,11 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     // of 1024: 46.6 us per launch against 47.5; through the library, alternating in one process
     // (tools/overlap_grid_ab.py, 25 rounds): regions of 20 launches -1.8 %, of 200 launches -1.4 %.  A launch on its own
     // (one queue, or the first of a chain) keeps the full grid: 53.5 us against 54.4.
-    // AETH_FIR_OVERLAP_GRID: 0 = always the full grid, 1 = three quarters whenever the lane is on, 2 = as described.
-    if (ctx->overlap && C::WG == 128) {
-        const int og = aeth::tuning_int("AETH_FIR_OVERLAP_GRID", 2);
-        if (og == 1 || (og == 2 && ctx->last_chained)) cap = cap * 3 / 4;
+    // Tuning (sixteenths of the resident grid): AETH_FIR_GRID_CHAINED for a launch beside its predecessor,
+    // AETH_FIR_GRID_FIRST for the first launch of a chain / a lone launch on a context with the lane on.
+    if (ctx->overlap && !ctx->stream_shared && C::WG == 128) {
+        const int num = ctx->last_chained ? aeth::tuning_int("AETH_FIR_GRID_CHAINED", 12) : aeth::tuning_int("AETH_FIR_GRID_FIRST", 16);
+        if (num > 0 && num < 16) cap = cap * num / 16;
     }
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
@@ -309,7 +311,7 @@ int aeth_fir_exec_decim(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in,
 
 }  // extern "C"
 
-namespace {
+namespace aeth {
 
 int fir_exec_on(aeth_fir *f, hipStream_t stream, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out)
 {
@@ -323,154 +325,9 @@ int fir_exec_on(aeth_fir *f, hipStream_t stream, const aeth_cf32 *hist, const ae
     return dispatch_fmi(f->ctx, f->fft_len, a, stream);
 }
 
-// Host-resident stream through the device in hop-aligned chunks: while one chunk is being filtered the next
-// crosses PCIe one way and the previous result the other.  The GPU-side counterpart of the reference's
-// thread-per-stage pipeline with pooled buffers (src/pipeline.rs:52-137, src/pool.rs:43-221) -- the stages are H2D copy | kernel |
-// D2H copy, each on its OWN HIP stream so that both copy engines stay busy back to back; the pool is three device
-// slots, handed from stage to stage by events (no host wait inside the loop).
-constexpr int kPipeSlots = 3;
-struct PipeSlot {
-    float2 *din = nullptr, *dout = nullptr;     // device: [history | chunk], chunk
-    hipEvent_t up = nullptr, ran = nullptr, down = nullptr;
-    bool used = false;
-};
-
-
-// hist: ntaps-1 host samples in front of `in` (null: zeros), as in aeth_fir_exec_host
-// util: per-stage active time as well (the device-side counterpart of the reference's per-stage utilisation
-// report, src/pipeline.rs:89-114): timed events around every stage operation, read back after the run
-int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats,
-                    aeth_pipe_util *util = nullptr)
-{
-    AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
-    if (util) *util = aeth_pipe_util{0, 0, 0, 0, 0, 0, 0};
-    if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0};
-    if (n == 0) return AETH_OK;
-    AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
-    AETH_REQUIRE(in != out, AETH_E_ARG, "FIR cannot run in place (blocks overlap)");
-    aeth_ctx *ctx = f->ctx;
-    aeth::DeviceGuard g(ctx->device);
-    const size_t nh = f->ntaps - 1;
-    if (chunk == 0) chunk = (size_t)4 << 20;                       // 32 MiB of samples per transfer
-    if (chunk > n) chunk = n;                                      // a short stream: slots no larger than it needs
-    chunk = ((chunk + f->hop - 1) / f->hop) * f->hop;              // hop-aligned: same blocks as the one-shot run
-    const size_t nchunks = (n + chunk - 1) / chunk;
-    // pin the caller's slices in place for true asynchronous copies (falls back to pageable copies)
-    // (only streams of 16 MiB and more: below that the copies take microseconds either way, and registering and
-    // unregistering short-lived caller buffers by the thousand is not something the runtime's own pinned-range cache
-    // for pageable copies needs to be mixed with; without pinning the pipeline runs at 1.5-2 GS/s instead of 5.7)
-    const bool want_pin = aeth::tuning_int("AETH_PIPE_PIN", 1) != 0 && n * sizeof(float2) >= ((size_t)16 << 20);
-    const bool pin_in = want_pin && hipHostRegister(const_cast<aeth_cf32 *>(in), n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
-    const bool pin_out = want_pin && hipHostRegister(out, n * sizeof(float2), hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
-    PipeSlot slot[kPipeSlots];
-    hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
-    int rc = AETH_OK;
-    auto fail = [&](hipError_t e, const char *what) { rc = aeth::hip_fail(e, what); };
-    auto ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) { fail(e, what); return false; } return true; };
-    const int nslots = (int)(nchunks < (size_t)kPipeSlots ? nchunks : (size_t)kPipeSlots);
-    for (int i = 0; i < 3 && rc == AETH_OK; i++)
-        if (!ctx->pipe_stream[i]) (void)ok(hipStreamCreateWithFlags(&ctx->pipe_stream[i], hipStreamNonBlocking), "hipStreamCreate");
-    s_up = ctx->pipe_stream[0]; s_run = ctx->pipe_stream[1]; s_down = ctx->pipe_stream[2];    // the context's, kept
-    for (int s = 0; s < nslots && rc == AETH_OK; s++) {
-        PipeSlot &sl = slot[s];
-        if (!ok(hipEventCreateWithFlags(&sl.up, hipEventDisableTiming), "hipEventCreate")) break;
-        if (!ok(hipEventCreateWithFlags(&sl.ran, hipEventDisableTiming), "hipEventCreate")) break;
-        if (!ok(hipEventCreateWithFlags(&sl.down, hipEventDisableTiming), "hipEventCreate")) break;
-        if (!ok(hipMalloc((void **)&sl.din, (chunk + nh) * sizeof(float2)), "hipMalloc")) break;
-        if (!ok(hipMalloc((void **)&sl.dout, chunk * sizeof(float2)), "hipMalloc")) break;
-    }
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (rc == AETH_OK) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipStreamSynchronize(aeth::ctx_stream(ctx)); (void)hipEventRecord(t0, s_up); }
-    // [chunk][stage][begin, end] -- only when the utilisation report is wanted
-    std::vector<hipEvent_t> marks;
-    if (util && rc == AETH_OK) {
-        marks.assign(nchunks * 6, nullptr);
-        for (auto &m : marks) if (!ok(hipEventCreate(&m), "hipEventCreate")) break;
-    }
-    auto mark = [&](size_t k, int stage, int end, hipStream_t st) {
-        if (!marks.empty() && rc == AETH_OK) (void)ok(hipEventRecord(marks[k * 6 + stage * 2 + end], st), "hipEventRecord");
-    };
-    for (size_t k = 0; k < nchunks && rc == AETH_OK; k++) {
-        PipeSlot &sl = slot[k % kPipeSlots];
-        const size_t o0 = k * chunk;
-        const size_t cnt = (n - o0 < chunk) ? n - o0 : chunk;
-        const size_t h = (o0 >= nh) ? nh : o0;                     // history samples available in the source
-        // H2D: the slot's input buffer is free once the kernel of chunk k - 3 has run
-        if (sl.used && !ok(hipStreamWaitEvent(s_up, sl.ran, 0), "hipStreamWaitEvent")) break;
-        mark(k, 0, 0, s_up);
-        // [zeros | history | chunk] -> device; the filter reads its history straight from the source slice
-        if (k == 0 && hist && nh) { if (!ok(hipMemcpyAsync(sl.din, hist, nh * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break; }
-        else if (h < nh && !ok(hipMemsetAsync(sl.din, 0, (nh - h) * sizeof(float2), s_up), "hipMemsetAsync")) break;
-        if (!ok(hipMemcpyAsync(sl.din + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
-        mark(k, 0, 1, s_up);
-        if (!ok(hipEventRecord(sl.up, s_up), "hipEventRecord")) break;
-        // kernel: needs the chunk up and the slot's output buffer drained by the D2H of chunk k - 3
-        if (!ok(hipStreamWaitEvent(s_run, sl.up, 0), "hipStreamWaitEvent")) break;
-        if (sl.used && !ok(hipStreamWaitEvent(s_run, sl.down, 0), "hipStreamWaitEvent")) break;
-        mark(k, 1, 0, s_run);
-        rc = fir_exec_on(f, s_run, (o0 || hist) ? (const aeth_cf32 *)sl.din : nullptr, (const aeth_cf32 *)(sl.din + nh), cnt, (aeth_cf32 *)sl.dout);
-        if (rc) break;
-        mark(k, 1, 1, s_run);
-        if (!ok(hipEventRecord(sl.ran, s_run), "hipEventRecord")) break;
-        // D2H
-        if (!ok(hipStreamWaitEvent(s_down, sl.ran, 0), "hipStreamWaitEvent")) break;
-        mark(k, 2, 0, s_down);
-        if (!ok(hipMemcpyAsync(out + o0, sl.dout, cnt * sizeof(float2), hipMemcpyDeviceToHost, s_down), "hipMemcpyAsync D2H")) break;
-        mark(k, 2, 1, s_down);
-        if (!ok(hipEventRecord(sl.down, s_down), "hipEventRecord")) break;
-        sl.used = true;
-    }
-    if (s_up) (void)hipStreamSynchronize(s_up);
-    if (s_run) (void)hipStreamSynchronize(s_run);
-    if (s_down) (void)hipStreamSynchronize(s_down);
-    if (rc == AETH_OK && (stats || util) && t0 && t1) {
-        // all three stage streams are idle now; time from the first enqueue to here
-        (void)hipEventRecord(t1, s_down); (void)hipEventSynchronize(t1);
-        float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1);
-        const double pinned = (pin_in ? 1 : 0) + (pin_out ? 2 : 0);
-        if (stats) { stats->seconds = ms * 1e-3; stats->samples = (double)n; stats->chunks = (double)nchunks; stats->pinned = pinned; }
-        if (util) {
-            util->seconds = ms * 1e-3; util->samples = (double)n; util->chunks = (double)nchunks; util->pinned = pinned;
-            double act[3] = {0, 0, 0};
-            for (size_t k = 0; k < nchunks && !marks.empty(); k++)
-                for (int st = 0; st < 3; st++) {
-                    float d = 0;
-                    if (hipEventElapsedTime(&d, marks[k * 6 + st * 2], marks[k * 6 + st * 2 + 1]) == hipSuccess) act[st] += d * 1e-3;
-                }
-            (void)hipGetLastError();
-            util->active_upload = act[0]; util->active_kernel = act[1]; util->active_download = act[2];
-        }
-    }
-    for (auto m : marks) if (m) (void)hipEventDestroy(m);
-    for (int s = 0; s < kPipeSlots; s++) {
-        if (slot[s].din) (void)hipFree(slot[s].din);
-        if (slot[s].dout) (void)hipFree(slot[s].dout);
-        if (slot[s].up) (void)hipEventDestroy(slot[s].up);
-        if (slot[s].ran) (void)hipEventDestroy(slot[s].ran);
-        if (slot[s].down) (void)hipEventDestroy(slot[s].down);
-    }
-    if (t0) (void)hipEventDestroy(t0);
-    if (t1) (void)hipEventDestroy(t1);
-    if (pin_in) (void)hipHostUnregister(const_cast<aeth_cf32 *>(in));
-    if (pin_out) (void)hipHostUnregister(out);
-    return rc;
-}
-
-}  // namespace
+}  // namespace aeth
 
 extern "C" {
-
-int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
-{
-    return fir_stream_host(f, nullptr, in, n, out, chunk, stats);
-}
-
-int aeth_fir_stream_host_util(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_util *util)
-{
-    AETH_REQUIRE(util, AETH_E_ARG, "util is null");
-    return fir_stream_host(f, nullptr, in, n, out, chunk, nullptr, util);
-}
 
 int aeth_fir_exec_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out)
 {

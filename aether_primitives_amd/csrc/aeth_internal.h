@@ -10,6 +10,8 @@
 
 #include "../../include/aether_hip.h"
 
+namespace aeth { struct PipeState; }
+
 struct aeth_ctx {
     int device = 0;
     hipStream_t stream_main = nullptr;   // use aeth::ctx_stream(ctx): it orders the caller behind the overlap lane
@@ -24,13 +26,15 @@ struct aeth_ctx {
     hipEvent_t ev_pre[2] = {nullptr, nullptr};   // [lane] recorded on that lane right before its latest FIR launch
     hipEvent_t ev_aux_done = nullptr;
     bool overlap = false;          // feature switch (off for borrowed streams)
+    bool stream_shared = false;    // aeth_ctx_stream() handed the main stream to code this library does not see: the
+                                   // lane stays out of use until aeth_ctx_set_overlap(ctx, 1) is called again
     bool aux_pending = false;      // the aux lane holds work the main stream is not yet ordered behind
     int chain_last = -1;           // lane of the latest FIR launch while nothing else has been enqueued since; else -1
     bool last_chained = false;     // the latest ctx_fir_lane call put its launch beside its predecessor
     uintptr_t last_in[2] = {0, 0}, last_out[2] = {0, 0};   // [lo, hi) byte ranges of that launch
-    // the three stage streams of the host pipeline (aeth_fir_stream_host), created on its first run and kept: a
-    // stream per stage per call would create and destroy three HIP streams for every stream filtered
-    hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};
+    // host pipeline (aeth_fir_stream_host): stage streams, device slots, events, pinned staging pool, copy threads --
+    // created on its first run and kept (aeth_host.h)
+    aeth::PipeState *pipe = nullptr;
     // device scratch of the host-slice flavours, grown on demand
     void *stage[2] = {nullptr, nullptr};
     size_t stage_bytes[2] = {0, 0};

@@ -2,6 +2,7 @@
 // Host-side runtime of libaether_hip.so; the GPU analogue of what the reference
 // keeps implicit in Rust ownership (Vec<cf32>, Cfft.tmp: src/fft.rs:134-159).
 #include "aeth_internal.h"
+#include "aeth_host.h"
 
 #include <chrono>
 #include <cstdlib>
@@ -59,7 +60,7 @@ static inline bool ranges_touch(uintptr_t a_lo, uintptr_t a_hi, uintptr_t b_lo, 
 
 hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintptr_t out_lo, uintptr_t out_hi)
 {
-    if (!ctx->overlap) return ctx_stream(ctx);
+    if (!ctx->overlap || ctx->stream_shared) return ctx_stream(ctx);
     const int prev = ctx->chain_last;
     bool chained = prev >= 0;
     if (chained) {
@@ -171,6 +172,7 @@ int aeth_ctx_set_overlap(aeth_ctx *ctx, int enable)
     }
     // a borrowed stream receives work this library does not see, so nothing can be reordered around it
     AETH_REQUIRE(ctx->owns_stream, AETH_E_UNSUPPORTED, "overlap needs a context that owns its stream");
+    ctx->stream_shared = false;                  // (re-)armed by the caller: whoever holds the stream pointer has been told
     if (ctx->overlap) return AETH_OK;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_pre[i], hipEventDisableTiming);
@@ -195,8 +197,7 @@ int aeth_ctx_destroy(aeth_ctx *ctx)
     aeth::DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(aeth::ctx_stream(ctx));
     overlap_release(ctx);
-    for (int i = 0; i < 3; i++)
-        if (ctx->pipe_stream[i]) { (void)hipStreamSynchronize(ctx->pipe_stream[i]); (void)hipStreamDestroy(ctx->pipe_stream[i]); }
+    aeth::pipe_release(ctx);
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     }
@@ -209,27 +210,52 @@ int aeth_ctx_sync(aeth_ctx *ctx)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
     aeth::DeviceGuard g(ctx->device);
-    hipStream_t s = aeth::ctx_stream(ctx);                       // the join puts the aux lane in front of this wait
+    // With work on the aux lane the host waits for BOTH queues itself instead of first enqueueing a join (event
+    // record on one queue, wait on the other) and then waiting for that: the join's two packets only run once the
+    // last kernel has ended and sit between it and the moment this call returns.  Once both queues are idle the
+    // lanes are trivially ordered, so the chain simply ends here.
+    hipStream_t waits[2] = {ctx->stream_main, nullptr};
+    int nw = 1;
+    if (ctx->aux_pending) { waits[nw++] = ctx->stream_aux; }
     // Short waits are polled: the wake-up latency of a blocking wait is a visible share of a millisecond-long
     // batch of launches.  After AETH_SYNC_SPIN_US (tuning; default 2000) the blocking wait takes over.
     const int spin_us = aeth::tuning_int("AETH_SYNC_SPIN_US", 2000);
+    bool done[2] = {false, false};
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
-            const hipError_t q = hipStreamQuery(s);
-            if (q == hipSuccess) return AETH_OK;
-            if (q != hipErrorNotReady) return aeth::hip_fail(q, "hipStreamQuery");
+            bool all = true;
+            for (int i = nw - 1; i >= 0; i--) {
+                if (done[i]) continue;
+                const hipError_t q = hipStreamQuery(waits[i]);
+                if (q == hipSuccess) done[i] = true;
+                else if (q == hipErrorNotReady) all = false;
+                else return aeth::hip_fail(q, "hipStreamQuery");
+            }
+            if (all) break;
             if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
         }
         (void)hipGetLastError();                                 // hipErrorNotReady is not an error
     }
-    AETH_HIP(hipStreamSynchronize(s));
+    for (int i = nw - 1; i >= 0; i--)
+        if (!done[i]) AETH_HIP(hipStreamSynchronize(waits[i]));
+    ctx->aux_pending = false;
+    ctx->chain_last = -1;
+    ctx->last_chained = false;
     return AETH_OK;
 }
 
-/* hands the stream to code this library does not see: joined first, and the overlap lane stays out of the way
- * only as long as every later call comes through the library again */
-void *aeth_ctx_stream(aeth_ctx *ctx) { return ctx ? (void *)aeth::ctx_stream(ctx) : nullptr; }
+/* Hands the stream to code this library does not see (torch ops on an ExternalStream, the caller's own copies):
+ * joined first, and from here on every launch stays on this one stream -- work the caller enqueues on it is ordered
+ * behind everything the library launched before AND after.  The overlap lane comes back only when the caller asks
+ * for it again (aeth_ctx_set_overlap(ctx, 1)), i.e. knows that launches may then run beside the stream it holds. */
+void *aeth_ctx_stream(aeth_ctx *ctx)
+{
+    if (!ctx) return nullptr;
+    hipStream_t s = aeth::ctx_stream(ctx);
+    if (ctx->overlap) ctx->stream_shared = true;
+    return (void *)s;
+}
 int aeth_ctx_device(const aeth_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 int aeth_dev_alloc(aeth_ctx *ctx, size_t bytes, void **dptr)

@@ -195,19 +195,40 @@ int aeth_host_interpolate(aeth_ctx *ctx, const aeth_cf32 *src, size_t n_src, aet
     return AETH_OK;
 }
 
-int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem)
+/* Which build of the reference an entry point matches (src/sampling.rs:32-36 is a debug_assert_eq!):
+ *   BUILD_DEBUG    `cargo build` / `cargo test`: the divisibility assert is compiled in and panics
+ *   BUILD_RELEASE  `cargo build --release` / `cargo bench` (benches/benches.rs:113,130 runs 8096 -> 512): the assert is
+ *                  compiled out, dec = src.len() / dst.len() floors and every dst[i] = src[i * dec] that stays inside
+ *                  src is taken; what still panics there is the division by zero of an empty dst, an index past the
+ *                  end of src (only an empty src can do that, since (n_dst - 1) * (n_src / n_dst) < n_src) and, for
+ *                  downsample_sb alone, step_by(0) when src is shorter than dst (:58-61) */
+enum { BUILD_DEBUG = 0, BUILD_RELEASE = 1 };
+
+static int downsample_check(size_t n_src, size_t n_dst, int build, int step_by)
+{
+    AETH_REQUIRE(n_dst > 0, AETH_E_LEN, "downsample into an empty dst (division by zero in the reference)");
+    if (build == BUILD_DEBUG) {
+        AETH_REQUIRE(n_src % n_dst == 0, AETH_E_LEN, AETH_MSG_DECIM);
+        /* 0 % n == 0 passes the reference's assert too; dec = 0 then reads src[0] of an empty slice and panics (:39-41) */
+        AETH_REQUIRE(n_src >= n_dst, AETH_E_LEN, "downsample from an empty src (the reference panics: index out of bounds)");
+    } else {
+        AETH_REQUIRE(n_src > 0, AETH_E_LEN, "downsample from an empty src (the reference panics: index out of bounds)");
+        AETH_REQUIRE(!step_by || n_src >= n_dst, AETH_E_LEN,
+                     "downsample_sb with src shorter than dst (the reference panics: step_by(0), sampling.rs:58-61)");
+    }
+    return AETH_OK;
+}
+
+static int downsample_dev(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem, int build, int step_by)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
-    AETH_REQUIRE(n_dst > 0, AETH_E_LEN, "downsample into an empty dst (division by zero in the reference)");
-    AETH_REQUIRE(n_src % n_dst == 0, AETH_E_LEN, AETH_MSG_DECIM);
-    /* 0 % n == 0 passes the reference's assert too; dec = 0 then reads src[0] of an empty slice and panics (:39-41) */
-    AETH_REQUIRE(n_src >= n_dst, AETH_E_LEN, "downsample from an empty src (the reference panics: index out of bounds)");
+    int rc = downsample_check(n_src, n_dst, build, step_by); if (rc) return rc;
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
     AETH_REQUIRE(elem == 1 || elem == 2 || elem == 4 || elem == 8 || elem == 16, AETH_E_ARG,
                  "elem_size %zu not in {1,2,4,8,16}", elem);
     AETH_REQUIRE(((uintptr_t)src % elem) == 0 && ((uintptr_t)dst % elem) == 0, AETH_E_ALIGN,
                  "pointer not aligned to elem_size");
-    const size_t dec = n_src / n_dst;
+    const size_t dec = n_src / n_dst;               /* :38 -- floors; 0 when src is shorter than dst (every dst[i] = src[0]) */
     aeth::DeviceGuard dev_guard(ctx->device);
     const dim3 g(grid_for(ctx, n_dst)), b(kBlock);
     const bool nt = aeth::streams_past_cache(n_dst * elem * 2);
@@ -228,22 +249,39 @@ int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, siz
     return AETH_OK;
 }
 
-int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem)
+static int downsample_host(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem, int build, int step_by)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
-    AETH_REQUIRE(n_dst > 0, AETH_E_LEN, "downsample into an empty dst (division by zero in the reference)");
-    AETH_REQUIRE(n_src % n_dst == 0, AETH_E_LEN, AETH_MSG_DECIM);
-    /* 0 % n == 0 passes the reference's assert too; dec = 0 then reads src[0] of an empty slice and panics (:39-41) */
-    AETH_REQUIRE(n_src >= n_dst, AETH_E_LEN, "downsample from an empty src (the reference panics: index out of bounds)");
+    int rc = downsample_check(n_src, n_dst, build, step_by); if (rc) return rc;
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
-    int rc = aeth::ctx_stage(ctx, 0, n_src * elem); if (rc) return rc;
+    rc = aeth::ctx_stage(ctx, 0, n_src * elem); if (rc) return rc;
     rc = aeth::ctx_stage(ctx, 1, n_dst * elem); if (rc) return rc;
     AETH_HIP(hipMemcpyAsync(ctx->stage[0], src, n_src * elem, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
-    rc = aeth_downsample(ctx, ctx->stage[0], n_src, ctx->stage[1], n_dst, elem);
+    rc = downsample_dev(ctx, ctx->stage[0], n_src, ctx->stage[1], n_dst, elem, build, step_by);
     if (rc) return rc;
     AETH_HIP(hipMemcpyAsync(dst, ctx->stage[1], n_dst * elem, hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
     AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     return AETH_OK;
+}
+
+int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem)
+{
+    return downsample_dev(ctx, src, n_src, dst, n_dst, elem, BUILD_DEBUG, 0);
+}
+
+int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem)
+{
+    return downsample_host(ctx, src, n_src, dst, n_dst, elem, BUILD_DEBUG, 0);
+}
+
+int aeth_downsample_release(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem, int step_by)
+{
+    return downsample_dev(ctx, src, n_src, dst, n_dst, elem, BUILD_RELEASE, step_by);
+}
+
+int aeth_host_downsample_release(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem, int step_by)
+{
+    return downsample_host(ctx, src, n_src, dst, n_dst, elem, BUILD_RELEASE, step_by);
 }
 
 }  // extern "C"

@@ -73,22 +73,29 @@ class Fir:
         return {"seconds": st.seconds, "samples": st.samples, "chunks": st.chunks, "pinned": st.pinned}
 
     def filter_stream(self, x, out=None, chunk=0, report=False):
-        """Host array through the device in hop-aligned chunks, upload | kernel | download on three streams (PCIe-rate path).
+        """Host array through the device in hop-aligned chunks: copy-in | upload | kernel | download | copy-out (PCIe-rate
+        path).  Arrays that live in pinned pool elements (aether_primitives_amd.pool) or registered ranges are copied
+        from / to directly; anything else is staged through the context's own pinned pool by host threads.
         Returns (y, stats) with stats = dict(seconds, samples, chunks, pinned); report=True adds the seconds each stage
-        was active and `lines`, the reference pipeline's per-stage report (pipeline.rs:101-108) for the three stages."""
+        was active and `lines`, the reference pipeline's per-stage report (pipeline.rs:101-108)."""
         x = np.ascontiguousarray(x, dtype=np.complex64)
         if out is None:
             out = np.empty_like(x)
+        assert out.dtype == np.complex64 and out.flags["C_CONTIGUOUS"] and out.size == x.size
         if report:
             class _Util(C.Structure):
-                _fields_ = [(k, C.c_double) for k in ("seconds", "samples", "chunks", "pinned", "active_upload", "active_kernel", "active_download")]
+                _fields_ = [(k, C.c_double) for k in ("seconds", "samples", "chunks", "pinned", "active_upload", "active_kernel",
+                                                      "active_download", "active_copy_in", "active_copy_out")]
             u = _Util()
             check(self._lib.aeth_fir_stream_host_util(self.h, x.ctypes.data_as(C.c_void_p), x.size,
                                                       out.ctypes.data_as(C.c_void_p), chunk, C.byref(u)))
             st = {k: getattr(u, k) for k, _ in _Util._fields_}
+            stages = [("copy-in", u.active_copy_in), ("upload", u.active_upload), ("kernel", u.active_kernel),
+                      ("download", u.active_download), ("copy-out", u.active_copy_out)]
+            # an empty stream runs nothing: no rates to print (seconds == 0)
             st["lines"] = [f"Stage: {name:15} : Processed {int(u.chunks)} in {u.seconds:3.3f}s ({u.chunks / u.seconds:9.2f}/s); "
                            f"Utilisation: {act / u.seconds * 100.0:3.2f}%"
-                           for name, act in (("upload", u.active_upload), ("kernel", u.active_kernel), ("download", u.active_download))]
+                           for name, act in stages if not (name.startswith("copy") and act == 0)] if u.seconds > 0 else []
             return out, st
 
         class _Stats(C.Structure):

@@ -36,17 +36,31 @@ def interpolate(ctx, src, dst, n_between, compat_im=True, frame_len=None):
     return n_written.value
 
 
-def downsample(ctx, src, dst):
-    """dst[i] = src[i * (len(src)/len(dst))] for any Copy element type (sampling.rs:28-42)."""
+def _downsample(ctx, src, dst, release, step_by):
     lib = _lib.load()
     if isinstance(src, DeviceVec):
-        check(lib.aeth_downsample(ctx.h, src._p(), src.n, dst._p(), dst.n, 8))
+        if release:
+            check(lib.aeth_downsample_release(ctx.h, src._p(), src.n, dst._p(), dst.n, 8, int(step_by)))
+        else:
+            check(lib.aeth_downsample(ctx.h, src._p(), src.n, dst._p(), dst.n, 8))
         return dst
     assert src.dtype == dst.dtype and src.flags["C_CONTIGUOUS"] and dst.flags["C_CONTIGUOUS"]
-    check(lib.aeth_host_downsample(ctx.h, src.ctypes.data_as(C.c_void_p), src.size,
-                                   dst.ctypes.data_as(C.c_void_p), dst.size, src.dtype.itemsize))
+    sp, dp = src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p)
+    if release:
+        check(lib.aeth_host_downsample_release(ctx.h, sp, src.size, dp, dst.size, src.dtype.itemsize, int(step_by)))
+    else:
+        check(lib.aeth_host_downsample(ctx.h, sp, src.size, dp, dst.size, src.dtype.itemsize))
     return dst
 
 
-# the step_by variant differs only in how the CPU iterates (sampling.rs:49-62)
-downsample_sb = downsample
+def downsample(ctx, src, dst, release=False):
+    """dst[i] = src[i * (len(src)/len(dst))] for any Copy element type (sampling.rs:28-42).
+    release=False is the reference's debug build (uneven sizes panic: debug_assert_eq!, :32-36); release=True its
+    release build, where the assert is compiled out and the ratio floors (benches/benches.rs:113: 8096 -> 512)."""
+    return _downsample(ctx, src, dst, release, False)
+
+
+def downsample_sb(ctx, src, dst, release=False):
+    """The step_by variant (sampling.rs:49-62): same results; a release build panics on step_by(0) when src is shorter
+    than dst, where `downsample` broadcasts src[0]."""
+    return _downsample(ctx, src, dst, release, True)

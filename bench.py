@@ -116,7 +116,9 @@ def cpu_baseline(budget_s=16.0):
                 break
         res[label] = done / el / 1e9
         res[label + "_n"] = done
+    # kind: "port" in the bench contract's vocabulary (reference | port); SURVEY 8d's name for it is the label
     return {"value": round(res["T"], 5), "unit": "GSamples/s", "cores": best_t, "kind": "port",
+            "label": "c++-restatement-of-rust-path",
             "value_1thread": round(res["1"], 5), "cpu_model": cpu_model(), "cores_visible": cores,
             "cgroup_cpu_quota": quota, "threads_tried": cands, "build": "gcc " + flags,
             "sample": f"oracle/aeth_oracle.c overlap-save chain (rfft->vec_mul->rifft, f32) over "
@@ -267,7 +269,9 @@ def side_workload(args):
         job_samples = n * n_channels
         name = "C4: 8 channels x (QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod), 4096 frames each" + (
             " (four calls)" if args.c4_unfused else " (modulate_awgn + mul_ifft_demod)")
-        bytes_ = 52 * n * len(mine)
+        # unfused: modulate 8 W + awgn 8 R + 8 W + correlate 8 R + 8 W + demod 8 R (+ 2 x 2 B of bits) = 52 B/sample;
+        # fused: modulate_awgn 2 R + 8 W, correlate + demod 8 R + 2 W = 20 B/sample
+        bytes_ = (52 if args.c4_unfused else 20) * n * len(mine)
         shard = f"channel_of: rank 0 runs channels {mine}"
     ranks.barrier(ctx)
     seen = ranks.ranks_seen()
@@ -355,19 +359,22 @@ def main():
     def barrier():
         ranks.barrier(ctx)
 
-    def timed(steps, first):
-        """barrier + sync | `steps` launches | sync: wall seconds (this rank) and HIP-event ms over the same region"""
-        e0, e1 = ctx.event(), ctx.event()
+    def timed(steps, first, events=False):
+        """barrier + sync | `steps` launches | sync: wall seconds (this rank); with events=True HIP events are recorded
+        around the launches as well (behind both queues) and their elapsed ms is returned too"""
+        e0, e1 = (ctx.event(), ctx.event()) if events else (None, None)
         barrier()
         t0 = time.perf_counter()
-        e0.record()
+        if events:
+            e0.record()
         for i in range(steps):
             step(first + i)
-        e1.record()
+        if events:
+            e1.record()
         ctx.sync()
         ranks.torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        return wall, e0.elapsed_ms(e1)
+        return wall, (e0.elapsed_ms(e1) if events else None)
 
     barrier()                  # RCCL sets its communicator up lazily: have that idle gap here, not next to the timed region
     seen = ranks.ranks_seen()
@@ -377,9 +384,16 @@ def main():
     nsettle = settle(step, ctx, args.settle_ms)
     for i in range(args.warmup):
         step(i)
-    elapsed, ev_ms = timed(args.steps, args.warmup)
-    step_ms = ev_ms / max(args.steps, 1)                      # per step, HIP events on the context's stream
+    # THE timed region (`value`, `ms_per_step`, `roofline.achieved` / `frac` all come from this one clock): barrier +
+    # sync | exactly K steps | sync + barrier, wall time, MAX over ranks.  Nothing but the K launches is enqueued inside.
+    elapsed, _ = timed(args.steps, args.warmup)
     elapsed = ranks.max_over_ranks(elapsed)
+    # The same K steps again with HIP events recorded around them on the context's stream (behind both queues):
+    # `roofline.frac_events`, the device-side view of the same region without the host's launch and wake-up latency.
+    for i in range(args.warmup):
+        step(i)
+    _, ev_ms = timed(args.steps, args.warmup, events=True)
+    step_ms = ev_ms / max(args.steps, 1)
 
     # Extra leg (rank 0's GPU, untimed for `value`): the same steps on ONE queue.  Per-launch kernel time as
     # rocprofv3 --kernel-trace sees it (profiles/): with two queues the dispatches overlap and their individual
@@ -389,7 +403,7 @@ def main():
         ctx.set_overlap(False)
         for i in range(max(args.warmup, 5)):
             step(i)
-        w1, e1 = timed(args.steps, args.warmup)
+        w1, e1 = timed(args.steps, args.warmup, events=True)
         ctx.set_overlap(True)
         k_ms = e1 / max(args.steps, 1)
         single = {"queues": 1, "kernel_ms": round(k_ms, 5),
@@ -414,7 +428,9 @@ def main():
         assert seen == args.gpus, f"collective spans {seen} ranks, --gpus says {args.gpus}"
         total_samples = float(STREAM) * args.steps * args.gpus
         value = total_samples / elapsed / 1e9
-        achieved = BYTES_PER_SAMPLE * STREAM / (step_ms * 1e-3) / 1e9
+        # per GPU, from the SAME clock as `value`: algorithmic bytes of one launch / (wall time of the region / K)
+        achieved = BYTES_PER_SAMPLE * STREAM / (elapsed / args.steps) / 1e9
+        achieved_ev = BYTES_PER_SAMPLE * STREAM / (step_ms * 1e-3) / 1e9
         traffic = measured_traffic() or (None, None)
         line = {
             "metric": "GSamples/s cf32 (FFT-2048 + 64-tap FIR chain)",
@@ -431,13 +447,17 @@ def main():
                                           "HIP queues, at most two launches in flight (aeth_ctx_set_overlap)")
                                          if overlap else "none: one queue, one launch at a time",
                        "parallelism": f"{args.gpus} independent stream(s), one per GPU, no collective"},
+            # frac == value / n_gpus * 16 B / 8 TB/s: same clock as `value` (the wall time of the timed region)
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "level": "step (HIP events over the timed region / steps)" + (
-                             "; two launches overlap, see single_queue for the per-dispatch duration" if overlap else ""),
+                         "level": "step: algorithmic bytes of one launch / (wall time of the timed region / steps), per GPU" + (
+                             "; two launches overlap, see per_dispatch_* for the duration of one dispatch" if overlap else ""),
+                         "achieved_events": round(achieved_ev, 1), "frac_events": round(achieved_ev / HBM_PEAK_GBS, 4),
+                         "events_note": "the same K steps repeated with HIP events recorded around them on the context's "
+                                        "stream, behind both queues (device-side time: no host launch / wake-up latency)",
                          "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
                          "traffic": traffic[1], "traffic_source": traffic[0],
-                         "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>>", "step_ms": round(step_ms, 5),
+                         "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>>", "step_ms_events": round(step_ms, 5),
                          "bytes_per_launch": BYTES_PER_SAMPLE * STREAM},
         }
         if single is not None:

@@ -49,6 +49,7 @@ typedef struct aeth_ctx aeth_ctx;       /* device + stream + staging buffers    
 typedef struct aeth_fft aeth_fft;       /* replaces Cfft (src/fft.rs:134-159)     */
 typedef struct aeth_fir aeth_fir;       /* gives Fir<T> (src/fir.rs:3-22) a body  */
 typedef struct aeth_event aeth_event;   /* hipEvent on the context's stream       */
+typedef struct aeth_pool aeth_pool;     /* replaces Pool<T> (src/pool.rs:71-160) for pinned host buffers */
 
 enum {
     AETH_OK = 0,
@@ -88,7 +89,10 @@ AETH_API int aeth_ctx_sync(aeth_ctx *ctx);
  * results are those of one in-order stream.  Off by default; refused for contexts on a borrowed stream. */
 AETH_API int aeth_ctx_set_overlap(aeth_ctx *ctx, int enable);
 AETH_API int aeth_ctx_overlap(const aeth_ctx *ctx);   /* 1 if enabled */
-AETH_API void *aeth_ctx_stream(aeth_ctx *ctx);       /* hipStream_t */
+/* hipStream_t of the context, for interop (torch ExternalStream, the caller's own copies and kernels).  Handing it out
+ * parks the overlap lane: every later launch stays on this stream, so work the caller enqueues on it is ordered behind
+ * the library's, until the caller re-arms the lane with aeth_ctx_set_overlap(ctx, 1). */
+AETH_API void *aeth_ctx_stream(aeth_ctx *ctx);
 AETH_API int aeth_ctx_device(const aeth_ctx *ctx);
 
 /* ---- device memory (caller-owned; the library never keeps host pointers) -- */
@@ -219,20 +223,46 @@ AETH_API int aeth_fir_exec_decim(aeth_fir *fir, const aeth_cf32 *hist_dev, const
 AETH_API int aeth_fir_exec_host(aeth_fir *fir, const aeth_cf32 *hist_host, const aeth_cf32 *in_host,
                                 size_t n, aeth_cf32 *out_host);
 
-/* Host-resident stream through the device at PCIe rate (SURVEY 8f "next" #4): hop-aligned
- * chunks, three device slots handed by events between an upload, a kernel and a download stream, so
- * that the H2D copy of chunk k+1, the kernel on chunk k and the D2H copy of chunk k-1 overlap and
- * both copy engines run back to back -- the device-side counterpart of the
- * reference's thread-per-stage pipeline over pooled buffers (src/pipeline.rs:52-137,
- * src/pool.rs:43-221).  Output is bit-identical to aeth_fir_exec_host on the whole slice.
- * chunk_samples = 0 picks 4 Mi samples.  stats may be NULL. */
+/* ---- pinned host buffers: src/pool.rs:43-221 -------------------------------------------------- */
+/* The reference's object pool ("useful for large buffers and other time expensive objects", :9-10) with pinned
+ * (hipHostMalloc) elements of elem_bytes each: the maker allocates one element, the resetter optionally zeroes it.
+ * Samples produced INTO pool elements (file reads, receivers, generators) cross PCIe with true asynchronous copies
+ * and no staging; the library never page-locks memory it did not allocate unless asked to (aeth_host_register).
+ * Thread-safe like the reference's Arc<Mutex<..>> (take / give_back from any thread). */
+enum { AETH_POOL_ZERO_ON_RETURN = 1 };                                  /* resetter: memset 0 (pool.rs:47,175-178) */
+AETH_API int aeth_pool_create(aeth_ctx *ctx, size_t elem_bytes, size_t initial_len, int flags, aeth_pool **out); /* pool::make :43-69 */
+AETH_API int aeth_pool_destroy(aeth_pool *pool);              /* refused (AETH_E_ARG) while elements are checked out   */
+AETH_API int aeth_pool_take(aeth_pool *pool, void **buf);     /* Pool::take :78-97: *buf = NULL when the pool is empty */
+AETH_API int aeth_pool_take_or_make(aeth_pool *pool, void **buf);       /* Pool::take_or_make :115-132 (grows the pool) */
+AETH_API int aeth_pool_give_back(aeth_pool *pool, void *buf); /* Elem::drop -> give_back :175-208                      */
+AETH_API size_t aeth_pool_len(aeth_pool *pool);               /* Pool::len :138-140: elements currently checked in     */
+AETH_API size_t aeth_pool_cap(aeth_pool *pool);               /* Pool::cap :157-159: elements the pool owns            */
+AETH_API size_t aeth_pool_elem_bytes(const aeth_pool *pool);
+/* Explicit opt-in for memory the caller owns (no reference counterpart): page-lock [ptr, ptr + bytes) so that the
+ * host pipeline copies from / to it directly.  The range must start on a page boundary and cover whole pages
+ * (AETH_E_ALIGN) and must not touch a pool element or a range registered before (AETH_E_ARG); every runtime return
+ * code is checked.  The caller keeps it alive and mapped until aeth_host_unregister has returned AETH_OK. */
+AETH_API int aeth_host_register(aeth_ctx *ctx, void *ptr, size_t bytes);
+AETH_API int aeth_host_unregister(aeth_ctx *ctx, void *ptr);
+AETH_API int aeth_host_is_pinned(const void *ptr, size_t bytes);        /* 1: inside one pool element / registered range */
+
+/* Host-resident stream through the device at PCIe rate (SURVEY 8f "next" #4): hop-aligned chunks through five
+ * stages -- copy-in (caller slice -> pinned pool element, host threads) | upload | kernel | download (three HIP
+ * streams, three device slots handed on by events) | copy-out (host threads) -- so that both copy engines run back to
+ * back: the counterpart of the reference's thread-per-stage pipeline over pooled buffers (src/pipeline.rs:52-137,
+ * src/pool.rs:43-221).  A side that is already page-locked (aeth_host_is_pinned: a pool element, a registered range)
+ * skips its host stage and is copied from / to directly.  Caller memory is never registered by this call.  Output is
+ * bit-identical to aeth_fir_exec_host on the whole slice.  chunk_samples = 0 picks 4 Mi samples (an eighth of the
+ * stream if that is less, at least 128 Ki).  stats may be NULL; stats->pinned = 1 * (in direct) + 2 * (out direct). */
 typedef struct { double seconds, samples, chunks, pinned; } aeth_pipe_stats;
 AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
                                   size_t chunk_samples, aeth_pipe_stats *stats);
 /* The same run with the per-stage report of the reference's pipeline (src/pipeline.rs:89-114: items processed, rate and
- * "Utilisation" = time active / time elapsed, per stage): seconds each of the three stages -- upload, kernel, download --
- * was busy, from timed events around every stage operation.  Utilisation of a stage = active_x / seconds. */
-typedef struct { double seconds, samples, chunks, pinned, active_upload, active_kernel, active_download; } aeth_pipe_util;
+ * "Utilisation" = time active / time elapsed, per stage): seconds each of the stages was busy -- upload, kernel, download
+ * from timed events around every stage operation, the two host stages from the wall clock between hand-over and completion
+ * of each chunk.  Utilisation of a stage = active_x / seconds. */
+typedef struct { double seconds, samples, chunks, pinned, active_upload, active_kernel, active_download,
+                 active_copy_in, active_copy_out; /* the two host stages (0 for a side copied directly) */ } aeth_pipe_util;
 AETH_API int aeth_fir_stream_host_util(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
                                        size_t chunk_samples, aeth_pipe_util *util);
 
@@ -268,6 +298,17 @@ AETH_API int aeth_downsample(aeth_ctx *ctx, const void *src_dev, size_t n_src,
                              void *dst_dev, size_t n_dst, size_t elem_size);
 AETH_API int aeth_host_downsample(aeth_ctx *ctx, const void *src, size_t n_src,
                                   void *dst, size_t n_dst, size_t elem_size);
+/* The two entry points above are the reference as `cargo build` / `cargo test` compile it (DEBUG build): the
+ * divisibility check of :32-36 is a debug_assert_eq! and panics there.  The two below are the reference as
+ * `cargo build --release` / `cargo bench` compile it (RELEASE build, the one its own benchmark runs at
+ * benches/benches.rs:113,130 with the shape 8096 -> 512): the assert is compiled out, dec = n_src / n_dst FLOORS and
+ * dst[i] = src[i*dec] for every i < n_dst (:38-41).  What still panics in a release build is an error here too
+ * (AETH_E_LEN): n_dst == 0 (division by zero), n_src == 0 (src[0] out of bounds); n_src < n_dst gives dec = 0, which
+ * downsample runs as dst[i] = src[0] and downsample_sb (step_by != 0) refuses, as step_by(0) panics (:58-61). */
+AETH_API int aeth_downsample_release(aeth_ctx *ctx, const void *src_dev, size_t n_src,
+                                     void *dst_dev, size_t n_dst, size_t elem_size, int step_by);
+AETH_API int aeth_host_downsample_release(aeth_ctx *ctx, const void *src, size_t n_src,
+                                          void *dst, size_t n_dst, size_t elem_size, int step_by);
 
 /* ---- modulation (SURVEY 8f "next" #1): src/modulation.rs --------------------------- */
 /* Modulation::modulate (:115-121): one symbol per `bits_per_symbol` input bytes (each byte is

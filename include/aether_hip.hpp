@@ -230,6 +230,53 @@ private:
     size_t n_;
 };
 
+// ---- pinned host buffers: pool::Pool<T> / Elem<T> (src/pool.rs:43-221) ------------------------------
+// Pool::make(ctx, n_samples, initial_len): elements are pinned buffers of n_samples cf32 each (the maker), optionally
+// zeroed on return (the resetter).  take() is empty (null Elem) when the pool is; take_or_make() grows it.  An Elem
+// derefs into its samples and returns itself to the pool when it goes out of scope (Elem::drop, :196-208).
+class Pool {
+public:
+    class Elem {
+    public:
+        Elem() = default;
+        Elem(aeth_pool *pool, cf32 *p, size_t n) : pool_(pool), p_(p), n_(n) {}
+        Elem(Elem &&o) noexcept : pool_(o.pool_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+        Elem &operator=(Elem &&o) noexcept { reset(); pool_ = o.pool_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; return *this; }
+        Elem(const Elem &) = delete;
+        Elem &operator=(const Elem &) = delete;
+        ~Elem() { reset(); }
+        explicit operator bool() const { return p_ != nullptr; }          // Option<Elem<T>>::is_some()
+        cf32 *data() { return p_; }
+        const cf32 *data() const { return p_; }
+        size_t size() const { return n_; }
+        cf32 &operator[](size_t i) { return p_[i]; }
+        void reset() { if (p_) { aeth_pool_give_back(pool_, p_); p_ = nullptr; } }
+    private:
+        aeth_pool *pool_ = nullptr;
+        cf32 *p_ = nullptr;
+        size_t n_ = 0;
+    };
+    static Pool make(Context &ctx, size_t n_samples, size_t initial_len, bool zero_on_return = false)
+    {
+        Pool p; p.n_ = n_samples;
+        check(aeth_pool_create(ctx.get(), n_samples * sizeof(cf32), initial_len, zero_on_return ? AETH_POOL_ZERO_ON_RETURN : 0, &p.h_));
+        return p;
+    }
+    Pool(Pool &&o) noexcept : h_(o.h_), n_(o.n_) { o.h_ = nullptr; }
+    Pool(const Pool &) = delete;
+    Pool &operator=(const Pool &) = delete;
+    ~Pool() { if (h_) aeth_pool_destroy(h_); }
+    Elem take() { void *b = nullptr; check(aeth_pool_take(h_, &b)); return Elem(h_, static_cast<cf32 *>(b), b ? n_ : 0); }
+    Elem take_or_make() { void *b = nullptr; check(aeth_pool_take_or_make(h_, &b)); return Elem(h_, static_cast<cf32 *>(b), n_); }
+    size_t len() const { return aeth_pool_len(h_); }
+    size_t cap() const { return aeth_pool_cap(h_); }
+    bool is_empty() const { return len() == 0; }
+private:
+    Pool() = default;
+    aeth_pool *h_ = nullptr;
+    size_t n_ = 0;
+};
+
 // ---- FIR (src/fir.rs:3-22 has the struct, not the filter) ------------------------------
 class Fir {
 public:
@@ -254,14 +301,27 @@ public:
         y.resize(x.size());
         aeth_pipe_util u{};
         check(aeth_fir_stream_host_util(h_, raw(x.data()), x.size(), raw(y.data()), chunk, &u));
-        if (report && u.seconds > 0) {
-            const char *names[3] = {"upload", "kernel", "download"};
-            const double act[3] = {u.active_upload, u.active_kernel, u.active_download};
-            for (int s = 0; s < 3; s++)
-                std::printf("Stage: %-15s : Processed %llu in %3.3fs (%9.2f/s); Utilisation: %3.2f%%\n", names[s],
-                            (unsigned long long)u.chunks, u.seconds, u.chunks / u.seconds, act[s] / u.seconds * 100.0);
-        }
+        if (report) print_report(u);
         return u;
+    }
+    // the same on raw slices: memory inside a pinned Pool element (or a registered range) is copied from / to directly
+    aeth_pipe_util filter_stream(const cf32 *x, size_t n, cf32 *y, size_t chunk = 0, bool report = false)
+    {
+        aeth_pipe_util u{};
+        check(aeth_fir_stream_host_util(h_, raw(x), n, raw(y), chunk, &u));
+        if (report) print_report(u);
+        return u;
+    }
+    static void print_report(const aeth_pipe_util &u)
+    {
+        if (!(u.seconds > 0)) return;
+        const char *names[5] = {"copy-in", "upload", "kernel", "download", "copy-out"};
+        const double act[5] = {u.active_copy_in, u.active_upload, u.active_kernel, u.active_download, u.active_copy_out};
+        for (int s = 0; s < 5; s++) {
+            if ((s == 0 || s == 4) && act[s] == 0) continue;       // a side that was copied directly has no host stage
+            std::printf("Stage: %-15s : Processed %llu in %3.3fs (%9.2f/s); Utilisation: %3.2f%%\n", names[s],
+                        (unsigned long long)u.chunks, u.seconds, u.chunks / u.seconds, act[s] / u.seconds * 100.0);
+        }
     }
     // the filter followed by sampling::downsample (sampling.rs:28-42) in one pass: y[i] = fir(x)[i * (x.len / y.len)]
     void filter_decim(const DeviceVec &x, DeviceVec &y, const DeviceVec *hist = nullptr)
@@ -287,13 +347,26 @@ inline void interpolate(Context &ctx, const std::vector<cf32> &src, std::vector<
     dst.resize(old + written);
 }
 
+// The reference checks divisibility with a debug_assert_eq! (sampling.rs:32-36): AETHER_REF_RELEASE_BUILD selects the
+// semantics of its release build (assert compiled out, ratio floors: what `cargo bench` runs, benches/benches.rs:113,130)
+// the way NDEBUG-less / --release selects them for the crate itself; the default mirrors `cargo test` (debug).
+#ifdef AETHER_REF_RELEASE_BUILD
+constexpr bool kRefReleaseBuild = true;
+#else
+constexpr bool kRefReleaseBuild = false;
+#endif
 template <typename T>
-inline void downsample(Context &ctx, const std::vector<T> &src, std::vector<T> &dst)
+inline void downsample(Context &ctx, const std::vector<T> &src, std::vector<T> &dst, bool release = kRefReleaseBuild)
 {
-    check(aeth_host_downsample(ctx.get(), src.data(), src.size(), dst.data(), dst.size(), sizeof(T)));
+    if (release) check(aeth_host_downsample_release(ctx.get(), src.data(), src.size(), dst.data(), dst.size(), sizeof(T), 0));
+    else check(aeth_host_downsample(ctx.get(), src.data(), src.size(), dst.data(), dst.size(), sizeof(T)));
 }
 template <typename T>
-inline void downsample_sb(Context &ctx, const std::vector<T> &src, std::vector<T> &dst) { downsample(ctx, src, dst); }
+inline void downsample_sb(Context &ctx, const std::vector<T> &src, std::vector<T> &dst, bool release = kRefReleaseBuild)
+{
+    if (release) check(aeth_host_downsample_release(ctx.get(), src.data(), src.size(), dst.data(), dst.size(), sizeof(T), 1));
+    else check(aeth_host_downsample(ctx.get(), src.data(), src.size(), dst.data(), dst.size(), sizeof(T)));
+}
 
 // ---- assert_evm! (src/lib.rs:26-49), literal, plus a NaN reject ---------------------------
 inline void assert_evm(const std::vector<cf32> &actual, const std::vector<cf32> &ref, double evm_limit_db = -80.0)

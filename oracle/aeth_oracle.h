@@ -108,6 +108,7 @@ size_t orc_interpolate(const orc_cf32 *src, size_t n_src, orc_cf32 *dst,
 /* :28-42 / :49-62.  dst[i] = src[i*dec], dec = n_src/n_dst, generic element
  * size.  Returns 0, or -1 when n_src % n_dst != 0 (debug_assert :32-36). */
 int orc_downsample(const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem_size);
+int orc_downsample_release(const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem_size, int step_by);
 
 /* ---- assert_evm!: src/lib.rs:26-49 ------------------------------------- */
 /* Literal macro: returns -1 if every element passes, else index of first

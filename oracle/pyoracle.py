@@ -92,6 +92,7 @@ def lib():
             "orc_correlate_frames": (i32, [vp, sz, vp, sz]),
             "orc_interpolate": (sz, [vp, sz, vp, sz, i32]),
             "orc_downsample": (i32, [vp, sz, vp, sz, sz]),
+            "orc_downsample_release": (i32, [vp, sz, vp, sz, sz, i32]),
             "orc_assert_evm": (C.c_long, [vp, sz, vp, sz, f64]),
             "orc_evm_worst_macro_db": (f64, [vp, vp, sz]),
             "orc_evm_aggregate_db": (f64, [vp, vp, sz]),
@@ -261,8 +262,14 @@ def interpolate(src, n_between, compat_im=True):
     return dst
 
 
-def downsample(src, n_dst):
+def downsample(src, n_dst, release=False, step_by=False):
+    """sampling::downsample (debug build: sampling.rs:28-42); release=True: the same function with the debug_assert
+    compiled out (what `cargo bench` runs, benches/benches.rs:113,130); step_by=True: downsample_sb (:49-62)."""
     src = np.ascontiguousarray(src); dst = np.empty(n_dst, src.dtype)
+    if release:
+        if lib().orc_downsample_release(_p(src), src.size, _p(dst), n_dst, src.dtype.itemsize, 1 if step_by else 0) != 0:
+            raise LengthMismatch("the reference panics (division by zero / index out of bounds / step_by(0))")
+        return dst
     if lib().orc_downsample(_p(src), src.size, _p(dst), n_dst, src.dtype.itemsize) != 0:
         raise LengthMismatch("Only even decimations are supported")
     return dst

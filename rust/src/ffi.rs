@@ -7,6 +7,8 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 #[repr(C)] pub struct aeth_fft { _p: [u8; 0] }
 #[repr(C)] pub struct aeth_fir { _p: [u8; 0] }
 #[repr(C)] pub struct aeth_event { _p: [u8; 0] }
+#[repr(C)] pub struct aeth_pool { _p: [u8; 0] }
+pub const AETH_POOL_ZERO_ON_RETURN: c_int = 1;
 /// aeth_pipe_stats: what the three-stage host-stream pipeline reports
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct aeth_pipe_stats { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64 }
@@ -15,7 +17,8 @@ pub struct aeth_pipe_stats { pub seconds: f64, pub samples: f64, pub chunks: f64
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct aeth_pipe_util { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64,
-                            pub active_upload: f64, pub active_kernel: f64, pub active_download: f64 }
+                            pub active_upload: f64, pub active_kernel: f64, pub active_download: f64,
+                            pub active_copy_in: f64, pub active_copy_out: f64 }
 
 pub const AETH_OK: c_int = 0;
 pub const AETH_E_LEN: c_int = -1;
@@ -107,6 +110,17 @@ extern "C" {
     pub fn aeth_fir_ntaps(fir: *const aeth_fir) -> usize;
     pub fn aeth_fir_fft_len(fir: *const aeth_fir) -> usize;
     pub fn aeth_fir_hop(fir: *const aeth_fir) -> usize;
+    pub fn aeth_pool_create(ctx: *mut aeth_ctx, elem_bytes: usize, initial_len: usize, flags: c_int, out: *mut *mut aeth_pool) -> c_int;
+    pub fn aeth_pool_destroy(pool: *mut aeth_pool) -> c_int;
+    pub fn aeth_pool_take(pool: *mut aeth_pool, buf: *mut *mut c_void) -> c_int;
+    pub fn aeth_pool_take_or_make(pool: *mut aeth_pool, buf: *mut *mut c_void) -> c_int;
+    pub fn aeth_pool_give_back(pool: *mut aeth_pool, buf: *mut c_void) -> c_int;
+    pub fn aeth_pool_len(pool: *mut aeth_pool) -> usize;
+    pub fn aeth_pool_cap(pool: *mut aeth_pool) -> usize;
+    pub fn aeth_pool_elem_bytes(pool: *const aeth_pool) -> usize;
+    pub fn aeth_host_register(ctx: *mut aeth_ctx, ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn aeth_host_unregister(ctx: *mut aeth_ctx, ptr: *mut c_void) -> c_int;
+    pub fn aeth_host_is_pinned(ptr: *const c_void, bytes: usize) -> c_int;
     pub fn aeth_fir_stream_host(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,
                                 stats: *mut aeth_pipe_stats) -> c_int;
     pub fn aeth_fir_stream_host_util(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,
@@ -137,6 +151,10 @@ extern "C" {
     pub fn aeth_rng_philox4x32_10(ctx: *mut aeth_ctx, ctr_key: *const u32, n: usize, out: *mut u32) -> c_int;
     pub fn aeth_host_downsample(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void,
                                 n_dst: usize, elem_size: usize) -> c_int;
+    pub fn aeth_downsample_release(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void, n_dst: usize,
+                                   elem_size: usize, step_by: c_int) -> c_int;
+    pub fn aeth_host_downsample_release(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void,
+                                        n_dst: usize, elem_size: usize, step_by: c_int) -> c_int;
 }
 
 /// Error convention: the reference panics (assert_eq!); the C ABI returns a code and a

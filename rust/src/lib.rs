@@ -149,9 +149,19 @@ pub mod sampling {
         unsafe { dst.set_len(dst.len() + written) };
     }
     /// `sampling::downsample<T: Copy>` (src/sampling.rs:28-42)
+    /// The reference's divisibility check is a `debug_assert_eq!` (:32-36): a debug build of this crate binds the
+    /// checked entry point, a release build the one that floors the ratio, exactly as the reference itself behaves
+    /// under `cargo test` and `cargo bench` (benches/benches.rs:113,130: 8096 -> 512).
     pub fn downsample<T: Copy>(ctx: &Context, src: &[T], dst: &mut [T]) {
-        check(unsafe { aeth_host_downsample(ctx.h, src.as_ptr() as *const c_void, src.len(),
-                                            dst.as_mut_ptr() as *mut c_void, dst.len(), std::mem::size_of::<T>()) });
+        let (s, d, e) = (src.as_ptr() as *const c_void, dst.as_mut_ptr() as *mut c_void, std::mem::size_of::<T>());
+        if cfg!(debug_assertions) { check(unsafe { aeth_host_downsample(ctx.h, s, src.len(), d, dst.len(), e) }); }
+        else { check(unsafe { aeth_host_downsample_release(ctx.h, s, src.len(), d, dst.len(), e, 0) }); }
+    }
+    /// `sampling::downsample_sb<T: Copy>` (src/sampling.rs:49-62): the step_by variant
+    pub fn downsample_sb<T: Copy>(ctx: &Context, src: &[T], dst: &mut [T]) {
+        let (s, d, e) = (src.as_ptr() as *const c_void, dst.as_mut_ptr() as *mut c_void, std::mem::size_of::<T>());
+        if cfg!(debug_assertions) { check(unsafe { aeth_host_downsample(ctx.h, s, src.len(), d, dst.len(), e) }); }
+        else { check(unsafe { aeth_host_downsample_release(ctx.h, s, src.len(), d, dst.len(), e, 1) }); }
     }
 }
 
@@ -177,12 +187,15 @@ impl<'c> Fir<'c> {
         check(unsafe { aeth_fir_stream_host(self.h, x.as_ptr(), x.len(), y.as_mut_ptr(), 0, &mut st) });
         st
     }
-    /// the same run, printing the reference pipeline's per-stage report (src/pipeline.rs:101-108) for the three device stages
+    /// the same run, printing the reference pipeline's per-stage report (src/pipeline.rs:101-108) for the device stages
+    /// and, when the slices had to be staged through the context's pinned pool, the two host stages
     pub fn filter_stream_report(&mut self, x: &[cf32], y: &mut [cf32]) -> aeth_pipe_util {
         assert_eq!(x.len(), y.len(), "Vectors must have same length");
         let mut u = aeth_pipe_util::default();
         check(unsafe { aeth_fir_stream_host_util(self.h, x.as_ptr(), x.len(), y.as_mut_ptr(), 0, &mut u) });
-        for (name, active) in [("upload", u.active_upload), ("kernel", u.active_kernel), ("download", u.active_download)].iter() {
+        for (name, active) in [("copy-in", u.active_copy_in), ("upload", u.active_upload), ("kernel", u.active_kernel),
+                               ("download", u.active_download), ("copy-out", u.active_copy_out)].iter() {
+            if name.starts_with("copy") && *active == 0.0 { continue; }
             println!("Stage: {:15} : Processed {} in {:3.3}s ({:9.2}/s); Utilisation: {:3.2}%",
                      name, u.chunks as u64, u.seconds, u.chunks / u.seconds, active / u.seconds * 100.0);
         }
@@ -190,6 +203,42 @@ impl<'c> Fir<'c> {
     }
 }
 impl<'c> Drop for Fir<'c> { fn drop(&mut self) { unsafe { aeth_fir_destroy(self.h); } } }
+
+/// Pinned host buffers behind the reference's `pool::Pool<T>` (src/pool.rs:43-221): `take`, `take_or_make`, `len`,
+/// `cap`; an `Elem` derefs into `[cf32]` and goes back to the pool on drop.  Elements are page-locked once by the
+/// library, so `Fir::filter_stream` copies from / to them directly (no staging, no registration of caller memory).
+pub struct PinnedPool<'c> { h: *mut aeth_pool, n: usize, _ctx: PhantomData<&'c Context> }
+pub struct PinnedElem<'p, 'c> { pool: &'p PinnedPool<'c>, p: *mut cf32 }
+impl<'c> PinnedPool<'c> {
+    /// `pool::make(initial_len, maker, resetter)` with maker = one pinned buffer of `n` samples
+    pub fn make(ctx: &'c Context, n: usize, initial_len: usize, zero_on_return: bool) -> PinnedPool<'c> {
+        let mut h = ptr::null_mut();
+        check(unsafe { aeth_pool_create(ctx.h, n * std::mem::size_of::<cf32>(), initial_len,
+                                        if zero_on_return { AETH_POOL_ZERO_ON_RETURN } else { 0 }, &mut h) });
+        PinnedPool { h, n, _ctx: PhantomData }
+    }
+    pub fn take(&self) -> Option<PinnedElem<'_, 'c>> {
+        let mut p = ptr::null_mut();
+        check(unsafe { aeth_pool_take(self.h, &mut p) });
+        if p.is_null() { None } else { Some(PinnedElem { pool: self, p: p as *mut cf32 }) }
+    }
+    pub fn take_or_make(&self) -> PinnedElem<'_, 'c> {
+        let mut p = ptr::null_mut();
+        check(unsafe { aeth_pool_take_or_make(self.h, &mut p) });
+        PinnedElem { pool: self, p: p as *mut cf32 }
+    }
+    pub fn len(&self) -> usize { unsafe { aeth_pool_len(self.h) } }
+    pub fn cap(&self) -> usize { unsafe { aeth_pool_cap(self.h) } }
+}
+impl<'c> Drop for PinnedPool<'c> { fn drop(&mut self) { unsafe { aeth_pool_destroy(self.h); } } }
+impl<'p, 'c> Drop for PinnedElem<'p, 'c> { fn drop(&mut self) { unsafe { aeth_pool_give_back(self.pool.h, self.p as *mut c_void); } } }
+impl<'p, 'c> std::ops::Deref for PinnedElem<'p, 'c> {
+    type Target = [cf32];
+    fn deref(&self) -> &[cf32] { unsafe { std::slice::from_raw_parts(self.p, self.pool.n) } }
+}
+impl<'p, 'c> std::ops::DerefMut for PinnedElem<'p, 'c> {
+    fn deref_mut(&mut self) -> &mut [cf32] { unsafe { std::slice::from_raw_parts_mut(self.p, self.pool.n) } }
+}
 
 /// `modulation::Modulation` for the generic BPSK/QPSK tables (src/modulation.rs:5-149) on device buffers,
 /// and `noise::Awgn::apply` (src/noise.rs:53-59).

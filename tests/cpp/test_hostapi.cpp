@@ -111,6 +111,16 @@ int main()
     });
     EXPECT_PANIC("downsample 7 -> 3", "Only even decimations are supported",
                  { std::vector<int> s(7), d(3); downsample(ctx, s, d); });
+    // the same call as the reference's RELEASE build runs it (debug_assert compiled out): benches/benches.rs:113,130
+    RUN("downsample 8096 -> 512, release-build semantics (dec = 15)", {
+        std::vector<cf32> src(8096), dst(512);
+        for (int i = 0; i < 8096; i++) src[i] = cf32((float)i, -(float)i);
+        downsample(ctx, src, dst, true);
+        for (int i = 0; i < 512; i++) if (dst[i] != src[15 * i]) throw Panic(0, "value");
+        std::fill(dst.begin(), dst.end(), cf32(0, 0));
+        downsample_sb(ctx, src, dst, true);
+        for (int i = 0; i < 512; i++) if (dst[i] != src[15 * i]) throw Panic(0, "value (step_by)");
+    });
 
     // FIR: impulse in, taps out
     RUN("fir impulse response", {
@@ -133,6 +143,30 @@ int main()
         if (z.size() != n || std::memcmp(y.data(), z.data(), n * sizeof(cf32)) != 0) throw Panic(0, "stream != one call");
         if (u.chunks != 8 || u.samples != (double)n || !(u.seconds > 0)) throw Panic(0, "stats");
         if (!(u.active_upload > 0 && u.active_kernel > 0 && u.active_download > 0)) throw Panic(0, "stage times");
+    });
+
+    // src/pool.rs:228-296 on pinned elements, then a stream produced into pool elements (copied directly, no staging)
+    RUN("pool: taking, taking_or_making, stream from pool elements", {
+        Pool pool = Pool::make(ctx, 1984 * 50, 1);
+        if (pool.len() != 1 || pool.cap() != 1) throw Panic(0, "make");
+        {
+            Pool::Elem c1 = pool.take();
+            if (!c1 || pool.len() != 0 || pool.cap() != 1) throw Panic(0, "First time checkout failed");
+            Pool::Elem c2 = pool.take();
+            if (c2) throw Panic(0, "Third checkout succeeded when it should have failed");
+        }
+        if (pool.len() != 1 || pool.cap() != 1) throw Panic(0, "drop returns the element");
+        Pool::Elem a = pool.take_or_make(), b = pool.take_or_make();
+        if (pool.len() != 0 || pool.cap() != 2) throw Panic(0, "take_or_make grows the pool");
+        std::vector<cf32> taps(64); for (int k = 0; k < 64; k++) taps[k] = cf32(1.0f / (k + 1), 0.01f * k);
+        const size_t n = a.size();
+        std::vector<cf32> x(n), y;
+        for (size_t i = 0; i < n; i++) { x[i] = cf32(std::sin(0.01f * i), std::cos(0.013f * i)); a[i] = x[i]; }
+        Fir fir(ctx, taps, 2048);
+        fir.filter(x, y);
+        const aeth_pipe_util u = fir.filter_stream(a.data(), n, b.data(), 1984 * 10);
+        if (u.pinned != 3 || u.active_copy_in != 0 || u.active_copy_out != 0) throw Panic(0, "pool elements must be copied directly");
+        if (std::memcmp(y.data(), b.data(), n * sizeof(cf32)) != 0) throw Panic(0, "stream != one call");
     });
 
     // overlap lane + decimating store: consecutive independent launches on two queues give the bits of the plain run

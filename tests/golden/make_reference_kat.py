@@ -114,6 +114,21 @@ cases += [
 cases += [
     dict(id="qpsk_table", src="src/modulation.rs:87-92,174-181", op="qpsk_modulate",
          bits=[0, 0, 1, 0, 0, 1, 1, 1], expect=seq([(1, 1), (-1, 1), (1, -1), (-1, -1)]), exact=True),
+    dict(id="generic_bpsk", src="src/modulation.rs:157-172", op="bpsk_modulate",
+         bits=[0, 1, 0, 1], expect=seq([(1, 1), (-1, -1), (1, 1), (-1, -1)]), exact=True),
+    # naive_demod (:184-196): `r.gen_range(0u8, 1u8)` is half-open, so every one of the 100 bits is 0 whatever the
+    # seed (815, 234354654543, 18324357): 50 x table[0] out of modulate, and demod_naive must give the 100 zeros back
+    dict(id="naive_demod", src="src/modulation.rs:184-196", op="qpsk_roundtrip", seeds=[815, 234354654543, 18324357],
+         bits=[0] * 100, expect=rep(1.0, 1.0, 50), expect_bits=[0] * 100, exact=True),
+]
+
+# ---- benches/benches.rs: the two downsample shapes the reference benchmarks (release build: the debug_assert of
+# sampling.rs:32-36 is compiled out, so 8096 -> 512 runs with dec = 15) -----------------------
+cases += [
+    dict(id="bench_downsample_30720_1024", src="benches/benches.rs:100-113", op="downsample_release_cf32",
+         self=rep(1.0, 1.0, 30720), n_dst=1024, dec=30, expect=rep(1.0, 1.0, 1024), exact=True),
+    dict(id="bench_downsample_8096_512", src="benches/benches.rs:100-113,130", op="downsample_release_cf32",
+         self=rep(1.0, 1.0, 8096), n_dst=512, dec=15, expect=rep(1.0, 1.0, 512), exact=True),
 ]
 
 doc = {

@@ -86,3 +86,31 @@ def test_borrowed_stream_context(ctx):
     del v
     c2.close()
     ctx.vec(rand_c64(1, 8)).vec_conj(); ctx.sync()               # the lender's stream is still alive
+
+
+def test_plan_temps_live_on_the_plans_device():
+    """A context on device 1 used from a process whose current device is 0: tfwd / tbwd and correlate + demod grow the
+    plan's temp on first use, and that allocation has to land on device 1 (fft_ensure_tmp sets the plan's device)."""
+    import ctypes as C
+    from aether_primitives_amd import _lib, modulation
+    from aether_primitives_amd.fft import Scale
+    from helpers import rand_c64, bits_equal
+    n = C.c_int()
+    _lib.check(_lib.load().aeth_device_count(C.byref(n)))
+    if n.value < 2:
+        pytest.skip("needs two visible GPUs")
+    c0, c1 = ap.Context(0), ap.Context(1)                      # the current device stays 0 (ctx_make restores it)
+    x = rand_c64(3, 512 * 4)
+    for c in (c0, c1):
+        f = ap.HipFft(c, 512, max_batch=1)                     # temp sized for one frame: four frames force a regrow
+        t = f.tfwd(c.vec(x), Scale.SN)
+        c.sync()
+    f0, f1 = ap.HipFft(c0, 512), ap.HipFft(c1, 512)
+    a, b = f0.tfwd(c0.vec(x), Scale.SN), f1.tfwd(c1.vec(x), Scale.SN)
+    assert bits_equal(a.to_host(), b.to_host())
+    q0, q1 = modulation.qpsk(c0), modulation.qpsk(c1)
+    sig = rand_c64(4, 512)
+    r0 = q0.correlate_demod(f0, c0.vec(x), c0.vec(sig)).to_host()       # 512 < 1024: the chain through the plan's temp
+    r1 = q1.correlate_demod(f1, c1.vec(x), c1.vec(sig)).to_host()
+    assert (r0 == r1).all()
+    c0.close(); c1.close()

@@ -16,8 +16,21 @@ def test_reference_qpsk_table(ctx):
     c = KAT["qpsk_table"]                                        # modulation.rs:174-181
     out = modulation.qpsk(ctx).modulate(np.array(c["bits"], np.uint8)).to_host()
     assert bits_equal(out, expand(c["expect"]))
-    out = modulation.bpsk(ctx).modulate(np.array([0, 1, 0, 1], np.uint8)).to_host()      # :157-172
-    assert bits_equal(out, np.array([1 + 1j, -1 - 1j, 1 + 1j, -1 - 1j], np.complex64))
+    b = KAT["generic_bpsk"]                                      # :157-172
+    out = modulation.bpsk(ctx).modulate(np.array(b["bits"], np.uint8)).to_host()
+    assert bits_equal(out, expand(b["expect"]))
+
+
+def test_reference_naive_demod(ctx):
+    """modulation.rs:184-196: bits from gen_range(0u8, 1u8) -- all zero whatever the seed -- through qpsk().modulate and
+    demod_naive (the QPSK specialisation, compat output) come back equal."""
+    c = KAT["naive_demod"]
+    q = modulation.qpsk(ctx)
+    bits = np.array(c["bits"], np.uint8)
+    for _seed in c["seeds"]:
+        sym = q.modulate(bits)
+        assert bits_equal(sym.to_host(), expand(c["expect"]))
+        assert q.demod_naive(sym, compat=True).to_host().tolist() == c["expect_bits"]
 
 
 @pytest.mark.parametrize("bps", [1, 2])

@@ -32,6 +32,37 @@ def test_overlap_refused_on_borrowed_stream(ctx):
     b.close()
 
 
+def test_handing_the_stream_out_parks_the_lane(octx, oracle):
+    """aeth_ctx_stream gives the main stream to code the library does not see (here: a second context that borrows it,
+    standing in for torch ops on an ExternalStream).  From then on every launch stays on that stream, so foreign work
+    enqueued on it is ordered behind later launches too; aeth_ctx_set_overlap(1) re-arms the lane."""
+    taps = oracle.synth_lowpass_taps(64, 0.25)
+    n = 1 << 20
+    f = Fir(octx, taps, 2048)
+    xs = [rand_c64(60 + i, n) for i in range(4)]
+    ins = [octx.vec(x) for x in xs]
+    outs = [octx.empty(n) for _ in xs]
+    want = [oracle.fir_ols_f32(taps, x, 2048, f.hop) for x in xs]
+    foreign = ap.Context(0, stream=octx.stream)                # the hand-over
+    lib = f._lib
+    for rep in range(3):
+        for i in range(4):
+            f.filter(ins[i], out=outs[i])                      # would alternate lanes if the lane were still in use
+        # foreign work on the borrowed stream, no sync, no library call on octx in between: reads what launches 2 and 3 wrote
+        from aether_primitives_amd._lib import check
+        check(lib.aeth_vec_add(foreign.h, outs[3]._p(), n, outs[2]._p(), n))
+        foreign.sync()
+        got = np.empty(n, np.complex64)
+        foreign.download(outs[3].ptr, got)
+        assert oracle.evm_db(got, oracle.vec_add(want[3], want[2])) <= -120
+    foreign.close()
+    octx.set_overlap(True)                                     # re-armed: chained launches use both queues again
+    for i in range(4):
+        f.filter(ins[i], out=outs[i])
+    for i in range(4):
+        assert oracle.evm_db(outs[i].to_host(), want[i]) <= -120
+
+
 def test_independent_launches_match_the_in_order_run(ctx, octx, oracle):
     taps = oracle.synth_lowpass_taps(64, 0.25)
     n = 1 << 20

@@ -73,6 +73,46 @@ def test_downsample_cf32_bit_exact(ctx, oracle, n_src, n_dst):
     assert bits_equal(d.to_host(), oracle.downsample(src, n_dst))
 
 
+@pytest.mark.parametrize("cid", ["bench_downsample_30720_1024", "bench_downsample_8096_512"])
+def test_downsample_release_build_bench_shapes(ctx, oracle, cid):
+    """The two shapes the reference benchmarks (benches/benches.rs:100-130; criterion = release build, where the
+    debug_assert of sampling.rs:32-36 is gone and 8096 -> 512 runs with dec = 15): the reference's constant input,
+    then seeded data against the oracle, both variants, device and host flavour."""
+    c = KAT[cid]
+    src, n_dst = expand(c["self"]), c["n_dst"]
+    for fn in (sampling.downsample, sampling.downsample_sb):
+        d = ctx.empty(n_dst)
+        fn(ctx, ctx.vec(src), d, release=True)
+        assert bits_equal(d.to_host(), expand(c["expect"]))
+        rnd = rand_c64(n_dst, src.size)
+        fn(ctx, ctx.vec(rnd), d, release=True)
+        assert bits_equal(d.to_host(), oracle.downsample(rnd, n_dst, release=True, step_by=fn is sampling.downsample_sb))
+        assert bits_equal(d.to_host(), rnd[::c["dec"]][:n_dst])
+        h = np.zeros(n_dst, np.complex64)
+        fn(ctx, rnd, h, release=True)
+        assert bits_equal(h, d.to_host())
+    if src.size % n_dst:
+        with pytest.raises(ap.LengthMismatch, match="Only even decimations"):       # the debug build of the same call
+            sampling.downsample(ctx, ctx.vec(src), ctx.empty(n_dst))
+
+
+def test_downsample_release_build_edges(ctx, oracle):
+    src = np.arange(7, dtype=np.int32)
+    for sb, fn in ((False, sampling.downsample), (True, sampling.downsample_sb)):
+        dst = np.zeros(3, np.int32)
+        fn(ctx, src, dst, release=True)                          # 7 -> 3 panics in the debug build only (:162-169)
+        assert dst.tolist() == oracle.downsample(src, 3, release=True, step_by=sb).tolist() == [0, 2, 4]
+        with pytest.raises(ap.LengthMismatch):
+            fn(ctx, src, np.zeros(0, np.int32), release=True)    # division by zero
+        with pytest.raises(ap.LengthMismatch):
+            fn(ctx, src[:0], np.zeros(4, np.int32), release=True)
+    dst = np.full(5, -1, np.int32)
+    sampling.downsample(ctx, src[1:3], dst, release=True)        # dec = 0: every dst[i] = src[0]
+    assert dst.tolist() == [1] * 5
+    with pytest.raises(ap.LengthMismatch, match="step_by"):
+        sampling.downsample_sb(ctx, src[1:3], dst, release=True)
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32, np.float64, np.complex128])
 def test_downsample_generic_element(ctx, oracle, dtype):
     rng = np.random.default_rng(3)

@@ -179,6 +179,49 @@ def test_qpsk_kat(oracle):
     assert d.tolist() == [0, 0, 1, 0, 0, 2, 1, 2]
 
 
+def test_generic_bpsk_kat(oracle):
+    c = KAT["generic_bpsk"]                                      # modulation.rs:157-172
+    assert bits_equal(oracle.modulate(np.array(c["bits"], np.uint8), 1), expand(c["expect"]))
+
+
+def test_naive_demod_kat(oracle):
+    """modulation.rs:184-196: 100 bits from gen_range(0u8, 1u8) (all zero for every seed) -> modulate -> demod_naive ->
+    the same bits, through the QPSK specialisation (:33-56) the test calls and the trait default (:133-144)."""
+    c = KAT["naive_demod"]
+    bits = np.array(c["bits"], np.uint8)
+    for _seed in c["seeds"]:
+        sym = oracle.qpsk_modulate(bits)
+        assert bits_equal(sym, expand(c["expect"]))
+        assert oracle.qpsk_demod_naive(sym).tolist() == c["expect_bits"]
+        assert oracle.demod_naive(sym, 2, compat=True).tolist() == c["expect_bits"]
+
+
+@pytest.mark.parametrize("cid", ["bench_downsample_30720_1024", "bench_downsample_8096_512"])
+def test_downsample_release_build_bench_shapes(oracle, cid):
+    """benches/benches.rs:100-130 (criterion = release build: the debug_assert of sampling.rs:32-36 is compiled out)"""
+    c = KAT[cid]
+    src = expand(c["self"])
+    for sb in (False, True):
+        assert bits_equal(oracle.downsample(src, c["n_dst"], release=True, step_by=sb), expand(c["expect"]))
+    ramp = np.arange(src.size, dtype=np.int32)                  # which elements are picked: i * (n_src / n_dst), floored
+    assert oracle.downsample(ramp, c["n_dst"], release=True).tolist() == [i * c["dec"] for i in range(c["n_dst"])]
+
+
+def test_downsample_release_build_edges(oracle):
+    src = np.arange(7, dtype=np.int32)
+    assert oracle.downsample(src, 3, release=True).tolist() == [0, 2, 4]                 # 7 -> 3 panics in debug only (:162-169)
+    assert oracle.downsample(src, 3, release=True, step_by=True).tolist() == [0, 2, 4]
+    assert oracle.downsample(src[:2], 5, release=True).tolist() == [0] * 5               # dec = 0: every dst[i] = src[0]
+    with pytest.raises(oracle.LengthMismatch):
+        oracle.downsample(src[:2], 5, release=True, step_by=True)                        # step_by(0) panics
+    with pytest.raises(oracle.LengthMismatch):
+        oracle.downsample(src, 0, release=True)                                          # division by zero
+    with pytest.raises(oracle.LengthMismatch):
+        oracle.downsample(src[:0], 4, release=True)                                      # src[0] of an empty slice
+    with pytest.raises(oracle.LengthMismatch):
+        oracle.downsample(src, 3)                                                        # the debug build still refuses
+
+
 def test_fir_ols_matches_direct_convolution(oracle):
     h = oracle.synth_lowpass_taps(64, 0.25)
     assert abs(h.sum() - 1) < 1e-6
