@@ -54,6 +54,8 @@ enum : int {
                     // (blockIdx % 8) take ADJACENT blocks of a round, so that the 63-sample halo a block shares with
                     // its neighbour is read through the same L2 -- round-robin over the XCDs spreads every region of
                     // the stream over all eight L2s and wins
+    V_SPREAD = 16384, // the next window's 16 loads issued in four groups between the passes of this block's forward
+                    // transform instead of one burst in front of it (the TA command FIFO is full 40 % of the time)
     V_DEMOD = 1024, // product variant: hard demodulation instead of the sample store (aeth_fft_mul_ifft_demod)
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
     V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
@@ -146,6 +148,21 @@ __device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a,
 #pragma unroll
     for (int m = 0; m < C::P; m++)
         x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
+}
+
+// the same, slots [M0, M1) only (V_SPREAD: the window arrives in four instalments)
+template <class C, bool NT, int M0, int M1>
+__device__ __forceinline__ void load_window_srd_part(cf (&x)[C::P], const FmiArgs &a, long long blk, int tid)
+{
+    const bool active = blk < a.nblocks;
+    const long long win0 = active ? blk * a.hop - a.ov : 0;
+    long long left = a.n - win0;
+    const int bytes = active ? (int)(left < a.frame_n ? left : a.frame_n) * 8 : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
+#pragma unroll
+    for (int m = M0; m < M1; m++)
+        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // V_TOUCH: one dword per 128-byte line of block `blk`'s window (plain cache policy: the line is meant to stay on
@@ -255,6 +272,26 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
 }
 
 // the chain on one block held in w[]: vec_rfft -> vec_mul -> vec_rifft (benches/benches.rs:410-416)
+// V_SPREAD form for three-pass configurations: nx[] = the window of block `gn`, loaded in four instalments
+template <class C, bool NT, int VAR>
+__device__ __forceinline__ void transform_block_spread(cf (&w)[C::P], cf (&nx)[C::P], const cf (&tw)[C::TW], const cf (&H)[C::P],
+                                                       cf *__restrict__ lds, const FmiArgs &a, long long gn, int tid)
+{
+    static_assert(C::NPASS == 3 && C::P % 4 == 0, "spread loads: three passes");
+    constexpr int XP = ((VAR & V_PRIO) ? 1 : 0) | ((VAR & V_XOR) ? 8 : 0);
+    constexpr int Q = C::P / 4;
+    load_window_srd_part<C, NT, 0, Q>(nx, a, gn, tid);
+    run_pass<C, 0, +1, 0, XP>(w, tw, lds, tid);
+    load_window_srd_part<C, NT, Q, 2 * Q>(nx, a, gn, tid);
+    run_pass<C, 1, +1, 0, XP>(w, tw, lds, tid);
+    load_window_srd_part<C, NT, 2 * Q, 3 * Q>(nx, a, gn, tid);
+    run_pass<C, 2, +1, 0, XP>(w, tw, lds, tid);
+#pragma unroll
+    for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);
+    load_window_srd_part<C, NT, 3 * Q, 4 * Q>(nx, a, gn, tid);
+    fft_in_regs<C, -1, fft_next_par<C>(0), XP>(w, tw, lds, tid);
+}
+
 template <class C, bool SCALED, bool BLU, int VAR>
 __device__ __forceinline__ void transform_block(cf (&w)[C::P], const cf (&tw)[C::TW], const cf (&H)[C::P],
                                                 cf *__restrict__ lds, const FmiArgs &a, int tid)
@@ -389,6 +426,8 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         if constexpr (VAR & V_NOLOAD) {
 #pragma unroll
             for (int m = 0; m < C::P; m++) asm volatile("" : "+v"(nx[m]));     // opaque, so that nothing folds
+        } else if constexpr (C::F == 1 && (VAR & V_SPREAD) && !SCALED && !BLU) {
+            // (loads issued inside transform_block_spread)
         } else if constexpr (C::F == 1) {
             // gn >= gridDim.x >= 1, so the window never starts before the stream: descriptor path
             load_window_srd<C, NT>(nx, a, gn, tid);
@@ -399,7 +438,8 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
             asm volatile("" ::"v"(tprev));      // issued a whole round ago: no wait
             tprev = touch_window<C>(a, g + (long long)TOUCH_AHEAD * gridDim.x, tid);
         }
-        transform_block<C, SCALED, BLU, VAR>(w, tw, H, lds, a, tid);
+        if constexpr (C::F == 1 && (VAR & V_SPREAD) && !SCALED && !BLU) transform_block_spread<C, NT, VAR>(w, nx, tw, H, lds, a, gn, tid);
+        else transform_block<C, SCALED, BLU, VAR>(w, tw, H, lds, a, tid);
         if constexpr (VAR & V_NOSTORE) {
 #pragma unroll
             for (int m = 0; m < C::P; m++) asm volatile("" ::"v"(w[m]));

@@ -209,9 +209,10 @@ def test_host_stream_pipeline_stage_report(ctx, taps):
     y, st = f.filter_stream(x, chunk=1 << 20, report=True)
     assert bits_equal(y, f.filter_stream(x, chunk=1 << 20)[0])
     assert st["chunks"] == -(-n // (((1 << 20) + f.hop - 1) // f.hop * f.hop))
-    for k in ("active_upload", "active_kernel", "active_download"):
-        assert 0 < st[k] <= st["seconds"] * 1.05, (k, st)
-    assert len(st["lines"]) == 3 and all(l.startswith("Stage: ") and "Utilisation:" in l for l in st["lines"])
+    for k in ("active_upload", "active_kernel", "active_download", "active_copy_in", "active_copy_out"):
+        assert 0 < st[k] <= st["seconds"] * 1.05, (k, st)          # pageable numpy memory: both host stages ran
+    assert st["pinned"] == 0
+    assert len(st["lines"]) == 5 and all(l.startswith("Stage: ") and "Utilisation:" in l for l in st["lines"])
 
 
 @pytest.mark.parametrize("n,dec", [(1984 * 4, 2), (30720, 30), (1 << 20, 8), (3_000_000, 3), (123456, 64), (1 << 24, 16)])

@@ -64,6 +64,7 @@ static void launch(int var, const FmiArgs &a, int grid, hipStream_t s, int any_o
     case 1432: launch_var2<176 + 256>(a, grid, s); break;
     case 432: launch_var<176 + 256>(a, grid, s, any_order); break;
     case 2052: launch_var<2048 + 4>(a, grid, s, any_order); break;
+    case 18436: launch_var<16384 + 2048 + 4>(a, grid, s, any_order); break;
     case 10244: launch_var<8192 + 2048 + 4>(a, grid, s, any_order); break;
     case 6148: launch_var<4096 + 2048 + 4>(a, grid, s, any_order); break;
     case 2048: launch_var<2048>(a, grid, s, any_order); break;
@@ -118,6 +119,7 @@ int main(int argc, char **argv)
         {"prio/2q+events", 4, 3, 0}, {"base/2q+events", 0, 3, 0},
         {"xor+prio+unroll2", 6148, 0, 0}, {"xor+prio+unroll2/2q", 6148, 2, 0},
         {"xor", 2048, 0, 0}, {"xor+prio", 2052, 0, 0}, {"xor+prio/2q", 2052, 2, 0}, {"xor+nomem", 2096, 0, 0},
+        {"xor+prio+spread", 18436, 0, 0}, {"xor+prio+spread/2q", 18436, 2, 0}, {"xor+prio+spread/g768/2q", 18436, 2, 768},
         {"xor+prio+xcd", 10244, 0, 0}, {"xor+prio+xcd/2q", 10244, 2, 0},
         {"xor+prio/g768/2q", 2052, 2, 768}, {"xor+prio/g896/2q", 2052, 2, 896}, {"xor+prio/g768", 2052, 0, 768},
         {"xor+prio/g704/2q", 2052, 2, 704}, {"xor+prio/g736/2q", 2052, 2, 736}, {"xor+prio/g800/2q", 2052, 2, 800},

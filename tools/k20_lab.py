@@ -43,7 +43,11 @@ if len(sys.argv) > 3:
     configs = [c for c in configs if any(a in c[0] for a in sys.argv[3:])]
 
 
-def region(overlap, first, chained, events):
+STAMPS = []
+
+
+def region(overlap, first, chained, events, k=None):
+    k = K if k is None else k
     os.environ["AETH_FIR_GRID_FIRST"] = str(first)
     os.environ["AETH_FIR_GRID_CHAINED"] = str(chained)
     ctx.set_overlap(overlap)
@@ -55,12 +59,16 @@ def region(overlap, first, chained, events):
     torch.cuda.synchronize(); ctx.sync()
     t0 = time.perf_counter()
     if events: e0.record()
-    for i in range(K):
+    for i in range(k):
         check(ex(*args[(WARM + i) % ns]))
+    t1 = time.perf_counter()
     if events: e1.record()
     ctx.sync()
+    t2 = time.perf_counter()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e6
+    t3 = time.perf_counter()
+    STAMPS.append(((t1 - t0) * 1e6, (t2 - t0) * 1e6, (t3 - t0) * 1e6))
+    return (t3 - t0) * 1e6
 
 
 # settle (load-onset power transient)
@@ -78,3 +86,25 @@ print(f"{'config':24} {'median':>9} {'min':>9} {'mean':>9} {'max':>9}   GS/s(med
 for c in configs:
     v = np.array(res[c[0]])
     print(f"{c[0]:24} {np.median(v):9.1f} {v.min():9.1f} {v.mean():9.1f} {v.max():9.1f}   {STREAM * K / np.median(v) / 1e3:10.1f} {STREAM * K / v.min() / 1e3:10.1f}")
+
+# where the region's wall time goes on the host side, default policy: enqueue done | ctx.sync done | torch sync done
+STAMPS.clear()
+for r in range(10):
+    region(True, 16, 12, False)
+a = np.median(np.array(STAMPS), axis=0)
+print(f"host stamps (median of 10, us from t0): {K} launches enqueued {a[0]:.1f} | aeth_ctx_sync returned {a[1]:.1f} | torch.cuda.synchronize returned {a[2]:.1f}")
+t0 = time.perf_counter()
+for i in range(200): torch.cuda.synchronize()
+print(f"torch.cuda.synchronize on an idle device: {(time.perf_counter() - t0) / 200 * 1e6:.2f} us;", end=" ")
+t0 = time.perf_counter()
+for i in range(200): ctx.sync()
+print(f"ctx.sync on an idle context: {(time.perf_counter() - t0) / 200 * 1e6:.2f} us")
+# fixed cost vs marginal cost of a launch: regions of different length, same protocol
+print("K sweep (default policy, median of 7 single-shot regions, wall us):")
+rows = []
+for k in (1, 2, 5, 10, 20, 40, 100, 200):
+    v = [region(True, 16, 12, False, k) for _ in range(7)]
+    rows.append((k, float(np.median(v)), float(np.min(v))))
+slope = (rows[-1][1] - rows[-2][1]) / (rows[-1][0] - rows[-2][0])
+for k, med, mn in rows:
+    print(f"   K = {k:3d}   median {med:9.1f}  min {mn:9.1f}   per launch {med / k:6.2f}   fixed (median - {slope:.2f} K) {med - slope * k:6.1f}")
