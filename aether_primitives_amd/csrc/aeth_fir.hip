@@ -94,6 +94,19 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
             return AETH_OK;
         }
     }
+    // A launch that runs on its own (one queue, or the head of a chain) issues the next window's loads in four
+    // instalments between the passes of the forward transform instead of one burst (V_SPREAD): 54.25 -> 53.34 us per
+    // 16 Mi-sample launch on one queue, bit-identical output; beside another launch the burst form wins (47.5 against
+    // 47.8 us), so chained launches keep it (profiles/r03_fir_lab_variants.txt).  AETH_FIR_SPREAD=0/1 forces either.
+    if constexpr (C::F == 1 && !SCALED && C::NPASS == 3) {
+        const int sp = aeth::tuning_int("AETH_FIR_SPREAD", -1);
+        const bool chained = ctx->overlap && !ctx->stream_shared && ctx->last_chained;
+        if (nt && (sp < 0 ? !chained : sp != 0)) {
+            hipLaunchKernelGGL((fmi_kernel<C, false, 1, true, false, VAR | V_SPREAD>), dim3(grid), dim3(C::WG), 0, stream, b);
+            AETH_HIP(hipGetLastError());
+            return AETH_OK;
+        }
+    }
     if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR>), dim3(grid), dim3(C::WG), 0, stream, b);
     else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false, VAR>), dim3(grid), dim3(C::WG), 0, stream, b);
     AETH_HIP(hipGetLastError());
