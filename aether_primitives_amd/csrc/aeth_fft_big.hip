@@ -158,8 +158,9 @@ __global__ __launch_bounds__(group_of<C0>() * C0::T) void fourstep_rows(const cf
 // aeth_fft_exec_interpolate therefore runs the two steps through the plan's temp.
 
 template <class C, int S>
-int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_total)
+int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_total, hipStream_t stream = nullptr, size_t work_off = 0)
 {
+    if (!stream) stream = aeth::ctx_stream(plan->ctx);
     const bool nt = aeth::streams_past_cache(plan->len * batch_total * sizeof(float2) * 4 / 3);   // from 96 MiB: x, a and X together pass the cache
     // 32 adjacent columns per workgroup (256-byte segments) where lanes and LDS allow (n1 <= 256): 512 x 65536 runs in
     // 169 us against 177 us with 16 (tools/tune_4step.py, AETH_4S_COLG), no difference on small batches
@@ -172,22 +173,23 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_tot
     auto kern = wide ? (nt ? fourstep_cols<C, S, true, 32> : fourstep_cols<C, S, false, 32>)
                 : half ? (nt ? fourstep_cols<C, S, true, 16, 512> : fourstep_cols<C, S, false, 16, 512>)
                        : (nt ? fourstep_cols<C, S, true, 16> : fourstep_cols<C, S, false, 16>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
-                       (const cf *)in, (cf *)plan->work_dev, (const cf *)plan->sub1->tw_lane_dev,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, stream,
+                       (const cf *)in, (cf *)(plan->work_dev + work_off), (const cf *)plan->sub1->tw_lane_dev,
                        aeth::tuning_int("AETH_4S_NOTW", 0) ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
 
 template <class C, int S>
-int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale, size_t batch_total)
+int launch_rows(aeth_fft *plan, float2 *out, size_t batch, float scale, size_t batch_total, hipStream_t stream = nullptr, size_t work_off = 0)
 {
+    if (!stream) stream = aeth::ctx_stream(plan->ctx);
     constexpr int G = group_of<C>();
     const size_t grid = batch * (plan->n1 / G);
     const bool nt = aeth::streams_past_cache(plan->len * batch_total * sizeof(float2) * 4 / 3);
     auto kern = nt ? fourstep_rows<C, S, true> : fourstep_rows<C, S, false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, aeth::ctx_stream(plan->ctx),
-                       (const cf *)plan->work_dev, (cf *)out, (const cf *)plan->sub2->tw_lane_dev, (int)plan->n1,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, stream,
+                       (const cf *)(plan->work_dev + work_off), (cf *)out, (const cf *)plan->sub2->tw_lane_dev, (int)plan->n1,
                        plan->len, scale);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
@@ -423,6 +425,49 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
     size_t gf = gmib ? gmib * ((size_t)1 << 20) / (plan->len * sizeof(float2)) : batch;
     if (gf < 1) gf = 1;
     if (gf > batch) gf = batch;
+    // Lab shape (round 3, AETH_4S_PARTS=2; measured, not kept -- profiles/r03_c5.json): frame groups dealt to TWO HIP
+    // streams, each running its groups' step A and step B back to back, so that one group's step B runs beside the
+    // other's step A (the fill of one launch under the drain of another, and a read-strided kernel beside a
+    // write-strided one); with AETH_4S_GROUP_MIB the two work-buffer regions stay cache-sized.
+    if (aeth::tuning_int("AETH_4S_PARTS", 1) == 2 && batch >= 2 && plan->n2 <= 4096) {
+        if (!gmib) gf = (batch + 1) / 2;
+        int rc = ensure_work(plan, plan->len * gf * 2);
+        if (rc) return rc;
+        aeth::DeviceGuard dg(plan->ctx->device);
+        static thread_local hipStream_t lab_stream = nullptr;
+        static thread_local hipEvent_t lab_ev[2] = {nullptr, nullptr};
+        if (!lab_stream) {
+            AETH_HIP(hipStreamCreateWithFlags(&lab_stream, hipStreamNonBlocking));
+            AETH_HIP(hipEventCreateWithFlags(&lab_ev[0], hipEventDisableTiming));
+            AETH_HIP(hipEventCreateWithFlags(&lab_ev[1], hipEventDisableTiming));
+        }
+        hipStream_t st[2] = {aeth::ctx_stream(plan->ctx), lab_stream};
+        AETH_HIP(hipEventRecord(lab_ev[0], st[0]));
+        AETH_HIP(hipStreamWaitEvent(st[1], lab_ev[0], 0));               // the second stream starts behind the context's work
+        size_t gi = 0;
+        for (size_t g0 = 0; g0 < batch; g0 += gf, gi++) {
+            const size_t cnt = batch - g0 < gf ? batch - g0 : gf;
+            const float2 *gin = in + g0 * plan->len;
+            float2 *gout = out + g0 * plan->len;
+            hipStream_t s = st[gi & 1];
+            const size_t off = (gi & 1) * gf * plan->len;
+#define AETH_BODY(NN)                                                                                   \
+    return sign > 0 ? launch_cols<typename CfgFor<NN>::type, +1>(plan, gin, cnt, batch, s, off)          \
+                    : launch_cols<typename CfgFor<NN>::type, -1>(plan, gin, cnt, batch, s, off)
+            auto cols = [&]() -> int { AETH_POW2_SWITCH(plan->n1, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n1")) };
+#undef AETH_BODY
+#define AETH_BODY(NN)                                                                                   \
+    return sign > 0 ? launch_rows<typename CfgFor<NN>::type, +1>(plan, gout, cnt, scale, batch, s, off)  \
+                    : launch_rows<typename CfgFor<NN>::type, -1>(plan, gout, cnt, scale, batch, s, off)
+            auto rows = [&]() -> int { AETH_POW2_SWITCH(plan->n2, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n2")) };
+#undef AETH_BODY
+            rc = cols(); if (rc) return rc;
+            rc = rows(); if (rc) return rc;
+        }
+        AETH_HIP(hipEventRecord(lab_ev[1], st[1]));
+        AETH_HIP(hipStreamWaitEvent(st[0], lab_ev[1], 0));               // and the context's stream continues behind it
+        return AETH_OK;
+    }
     int rc = ensure_work(plan, plan->len * gf);
     if (rc) return rc;
     for (size_t g0 = 0; g0 < batch; g0 += gf) {

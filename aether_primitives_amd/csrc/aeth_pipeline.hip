@@ -234,6 +234,7 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
         o0 = k * chunk; cnt = (n - o0 < chunk) ? n - o0 : chunk; h = (o0 >= nh) ? nh : o0;     // h: history samples the source holds
     };
 
+    int idle = 0;
     while (rc == AETH_OK && (next_sub < nchunks || (stage_out && fin_out < nchunks))) {
         bool progress = false;
         // ---- copy-in: chunk k into its slot's pinned element once the upload of chunk k - 3 has left it
@@ -309,7 +310,11 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
             } else if (q != hipErrorNotReady) { fail(q, "hipEventQuery"); break; }
         }
         while (stage_out && fin_out < next_out && out_pending[fin_out].load(std::memory_order_acquire) == 0) { act_out += now_s() - t_out[fin_out]; fin_out++; progress = true; }
-        if (!progress) std::this_thread::yield();
+        // nothing moved: a chunk takes hundreds of microseconds, so back off instead of hammering the runtime with
+        // event queries (its completion handling shares locks with them)
+        if (progress) idle = 0;
+        else if (++idle < 32) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
     (void)hipGetLastError();                                       // hipErrorNotReady from the queries is not an error
     // drain: the device stages, then whatever the copy threads still hold (also on the error path: they write
