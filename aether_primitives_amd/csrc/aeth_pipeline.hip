@@ -197,7 +197,12 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
 
     // a side that is already page-locked is copied from / to directly; anything else goes through pinned staging
     const bool stage_in = !aeth::host_range_pinned(in, n * sizeof(float2));
-    const bool stage_out = !aeth::host_range_pinned(out, n * sizeof(float2));
+    bool stage_out = !aeth::host_range_pinned(out, n * sizeof(float2));
+    // A staged input next to a directly written output is the one combination that measured badly: with 256 Mi
+    // samples the downloads into the caller's (pinned) 2 GiB slice took 2.4 x as long while the copy threads fed the
+    // uploads (2.3-2.9 GS/s, profiles/r03_stream_host.txt; cause not found), where staging BOTH sides runs at the
+    // rate of the all-pinned case (5.6 GS/s) -- so an input that needs the host stage takes the output through it too.
+    if (stage_in && !stage_out && aeth::tuning_int("AETH_PIPE_MIXED", 0) == 0) stage_out = true;
 
     int rc = pipe_prepare(ctx, in_slot_bytes, out_slot_bytes, nslots);
     if (rc) return rc;

@@ -457,7 +457,7 @@ def main():
                                         "stream, behind both queues (device-side time: no host launch / wake-up latency)",
                          "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
                          "traffic": traffic[1], "traffic_source": traffic[0],
-                         "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>>", "step_ms_events": round(step_ms, 5),
+                         "kernel": "fmi_kernel<Cfg<2048,16,16,16,8>> (V_PRIO|V_XOR; +V_SPREAD for a launch that runs alone)", "step_ms_events": round(step_ms, 5),
                          "bytes_per_launch": BYTES_PER_SAMPLE * STREAM},
         }
         if single is not None:

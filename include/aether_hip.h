@@ -253,7 +253,8 @@ AETH_API int aeth_host_is_pinned(const void *ptr, size_t bytes);        /* 1: in
  * src/pool.rs:43-221).  A side that is already page-locked (aeth_host_is_pinned: a pool element, a registered range)
  * skips its host stage and is copied from / to directly.  Caller memory is never registered by this call.  Output is
  * bit-identical to aeth_fir_exec_host on the whole slice.  chunk_samples = 0 picks 4 Mi samples (an eighth of the
- * stream if that is less, at least 128 Ki).  stats may be NULL; stats->pinned = 1 * (in direct) + 2 * (out direct). */
+ * stream if that is less, at least 128 Ki).  stats may be NULL; stats->pinned = 1 * (in direct) + 2 * (out direct); an
+ * input that needs staging takes the output through the host stage as well (measured: the mixed form is the slow one). */
 typedef struct { double seconds, samples, chunks, pinned; } aeth_pipe_stats;
 AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
                                   size_t chunk_samples, aeth_pipe_stats *stats);

@@ -92,8 +92,8 @@ def test_stream_from_pool_elements_is_direct_and_bit_identical(ctx, n):
         _, st = f.filter_stream(xin, out=z)
         assert st["pinned"] == 1 and bits_equal(z, want)
         y[:] = 0
-        _, st = f.filter_stream(x, out=y)
-        assert st["pinned"] == 2 and bits_equal(y, want)
+        _, st = f.filter_stream(x, out=y)                      # a staged input takes the output through the host stage too
+        assert st["pinned"] == 0 and bits_equal(y, want)
     z, st = f.filter_stream(x, report=True)
     assert st["pinned"] == 0 and bits_equal(z, want)
     assert st["active_copy_in"] > 0 and st["active_copy_out"] > 0 and len(st["lines"]) == 5

@@ -23,7 +23,7 @@ def newest(pat):
 def kname(s):
     return "fourstep_cols" if "fourstep_cols" in s else "fourstep_rows" if "fourstep_rows" in s else None
 shapes = {}
-for d in sorted(glob.glob(os.path.join(src, "shape*"))):
+for d in sorted(glob.glob(os.path.join(src, "shape[0-9]*"))):
     name = open(os.path.join(d, "name.txt")).read().strip()
     kern = {}
     st = newest(os.path.join(d, "trace/*/*_kernel_stats.csv"))
