@@ -1,5 +1,5 @@
 // aeth_rng.h -- counter-based complex normal generator used by the AWGN kernel.
-// Plain C, integer + f32 (+,-,*,/,sqrt) only, fixed operation order: compiled with
+// Plain C, integer + f32 (+,-,*,/,sqrt, explicit fmaf) only, fixed operation order: compiled with
 // -ffp-contract=off it is bit-reproducible between host compilers and the GPU.
 #pragma once
 #include <math.h>
@@ -11,12 +11,17 @@
 /* ---- counter-based complex normal generator (the BUILD's own; the reference's
  * StdRng + rand_distr::Normal stream, src/noise.rs:2-4,29-44, cannot be reproduced).
  * Philox4x32-10 keyed by the seed, counter = pair index; one call -> four 32-bit words ->
- * two complex samples by Box-Muller.  Every floating-point step is +,-,*,sqrt on f32 in a
- * fixed order (no libm), so CPU oracle and GPU kernel agree bit for bit when both are
- * compiled without contraction. ---- */
+ * two complex samples by Box-Muller.  Every floating-point step is +, -, *, /, sqrt or an
+ * EXPLICIT fmaf (correctly rounded by definition, one instruction on the GPU) on f32 in a fixed
+ * order -- no transcendental libm call -- so CPU oracle and GPU kernel agree bit for bit when
+ * both are compiled without implicit contraction.  (Round 3: the polynomial steps became fmaf and
+ * the quadrant selection branch-free; the generator's low-order bits changed with that.) ---- */
 AETH_RNG_FN void aeth_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                     uint32_t out[4])
 {
+#if defined(__clang__)
+#pragma unroll
+#endif
     for (int r = 0; r < 10; r++) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
@@ -35,15 +40,17 @@ AETH_RNG_FN float aeth_rng_log(float u)
     int e = (int)((v.i >> 23) & 0xff) - 127;
     v.i = (v.i & 0x007fffffu) | 0x3f800000u;               /* m in [1, 2) */
     float m = v.f;
-    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const int hi = m > 1.41421356f;                         /* fold [sqrt 2, 2) onto [sqrt .5, 1) */
+    m = hi ? m * 0.5f : m;
+    e += hi;
     const float s = (m - 1.0f) / (m + 1.0f);
     const float s2 = s * s;
     float p = 0.11111111f;                                  /* 1/9 */
-    p = p * s2 + 0.14285715f;                               /* 1/7 */
-    p = p * s2 + 0.2f;
-    p = p * s2 + 0.33333334f;
-    p = p * s2 + 1.0f;
-    return (float)e * 0.69314718f + 2.0f * s * p;
+    p = fmaf(p, s2, 0.14285715f);                           /* 1/7 */
+    p = fmaf(p, s2, 0.2f);
+    p = fmaf(p, s2, 0.33333334f);
+    p = fmaf(p, s2, 1.0f);
+    return fmaf((float)e, 0.69314718f, (2.0f * s) * p);
 }
 
 /* (cos, sin)(2 pi w / 2^24), w a 24-bit integer: quadrant by the top two bits, then
@@ -54,22 +61,25 @@ AETH_RNG_FN void aeth_rng_cossin(uint32_t w24, float *c, float *s)
     const float t = (float)(w24 & 0x3fffffu) * (1.0f / 4194304.0f);
     const float x = t * 1.57079633f, x2 = x * x;
     float sp = -2.50521084e-08f;                            /* -1/11! */
-    sp = sp * x2 + 2.75573192e-06f;
-    sp = sp * x2 - 1.98412698e-04f;
-    sp = sp * x2 + 8.33333333e-03f;
-    sp = sp * x2 - 1.66666667e-01f;
-    sp = sp * x2 + 1.0f;
+    sp = fmaf(sp, x2, 2.75573192e-06f);
+    sp = fmaf(sp, x2, -1.98412698e-04f);
+    sp = fmaf(sp, x2, 8.33333333e-03f);
+    sp = fmaf(sp, x2, -1.66666667e-01f);
+    sp = fmaf(sp, x2, 1.0f);
     sp = sp * x;
     float cp = -2.75573192e-07f;                            /* -1/10! */
-    cp = cp * x2 + 2.48015873e-05f;
-    cp = cp * x2 - 1.38888889e-03f;
-    cp = cp * x2 + 4.16666667e-02f;
-    cp = cp * x2 - 0.5f;
-    cp = cp * x2 + 1.0f;
-    if (q == 0) { *c = cp; *s = sp; }
-    else if (q == 1) { *c = -sp; *s = cp; }
-    else if (q == 2) { *c = -cp; *s = -sp; }
-    else { *c = sp; *s = -cp; }
+    cp = fmaf(cp, x2, 2.48015873e-05f);
+    cp = fmaf(cp, x2, -1.38888889e-03f);
+    cp = fmaf(cp, x2, 4.16666667e-02f);
+    cp = fmaf(cp, x2, -0.5f);
+    cp = fmaf(cp, x2, 1.0f);
+    /* quadrant: (cp, sp), (-sp, cp), (-cp, -sp), (sp, -cp) -- a select and a sign-bit flip each, no branches */
+    union { float f; uint32_t i; } a, b;
+    a.f = (q & 1u) ? sp : cp;
+    b.f = (q & 1u) ? cp : sp;
+    a.i ^= (((q + 1u) >> 1) & 1u) << 31;                    /* cos is negative in quadrants 1 and 2 */
+    b.i ^= (q >> 1) << 31;                                  /* sin in quadrants 2 and 3 */
+    *c = a.f; *s = b.f;
 }
 
 /* two 32-bit words -> one complex standard normal (unit variance per component) */
