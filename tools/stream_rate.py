@@ -29,8 +29,10 @@ def run(kind, n, chunk=0, report=False):
     y = ybig[:n] if kind == "pageable" else eout.array(np.complex64, n)
     best = None
     for rep in range(5):
-        _, st = fir.filter_stream(x, out=y, chunk=chunk, report=report and rep == 4)
+        _, st = fir.filter_stream(x, out=y, chunk=chunk)
         if best is None or st["seconds"] < best["seconds"]: best = st
+    if report:
+        best = dict(best, lines=fir.filter_stream(x, out=y, chunk=chunk, report=True)[1]["lines"])
     return y, best
 
 
