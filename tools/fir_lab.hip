@@ -34,7 +34,8 @@ static const int NBUF = 6;
 struct Variant {
     const char *name;
     int var;          // kernel template VAR
-    int mode;         // 0 plain launch, 1 hipExtAnyOrderLaunch, 2 two streams alternating, 3 the same with the library's event protocol
+    int mode;         // 0 plain launch, 1 hipExtAnyOrderLaunch, 2 two streams alternating, 3 the same with the library's event protocol,
+                      // 4 / 5 / 6: three / four / six streams round-robin (no events: the lab's buffers make the launches independent)
     int grid;         // 0 = default
 };
 
@@ -120,6 +121,10 @@ int main(int argc, char **argv)
         {"xor+prio+unroll2", 6148, 0, 0}, {"xor+prio+unroll2/2q", 6148, 2, 0},
         {"xor", 2048, 0, 0}, {"xor+prio", 2052, 0, 0}, {"xor+prio/2q", 2052, 2, 0}, {"xor+nomem", 2096, 0, 0},
         {"xor+prio+spread", 18436, 0, 0}, {"xor+prio+spread/2q", 18436, 2, 0}, {"xor+prio+spread/g768/2q", 18436, 2, 768},
+        {"xor+prio/g768/3q", 2052, 4, 768}, {"xor+prio/g768/4q", 2052, 5, 768}, {"xor+prio/g768/6q", 2052, 6, 768},
+        {"xor+prio/g640/3q", 2052, 4, 640}, {"xor+prio/g640/4q", 2052, 5, 640}, {"xor+prio/g512/3q", 2052, 4, 512}, {"xor+prio/g512/4q", 2052, 5, 512},
+        {"xor+prio/g896/3q", 2052, 4, 896}, {"xor+prio/g1024/3q", 2052, 4, 0}, {"xor+prio/g1024/4q", 2052, 5, 0},
+        {"xor+prio/g384/4q", 2052, 5, 384}, {"xor+prio/g384/6q", 2052, 6, 384}, {"xor+prio/g512/6q", 2052, 6, 512},
         {"xor+prio+xcd", 10244, 0, 0}, {"xor+prio+xcd/2q", 10244, 2, 0},
         {"xor+prio/g768/2q", 2052, 2, 768}, {"xor+prio/g896/2q", 2052, 2, 896}, {"xor+prio/g768", 2052, 0, 768},
         {"xor+prio/g704/2q", 2052, 2, 704}, {"xor+prio/g736/2q", 2052, 2, 736}, {"xor+prio/g800/2q", 2052, 2, 800},
@@ -138,8 +143,10 @@ int main(int argc, char **argv)
 
     aeth_ctx *ctx = nullptr;
     AK(aeth_ctx_create(0, &ctx));
-    hipStream_t s0 = (hipStream_t)aeth_ctx_stream(ctx), s1;
+    hipStream_t s0 = (hipStream_t)aeth_ctx_stream(ctx), s1, sx[6];
     CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    sx[0] = s0; sx[1] = s1;
+    for (int i = 2; i < 6; i++) CK(hipStreamCreateWithFlags(&sx[i], hipStreamNonBlocking));
 
     // taps: 64-tap Hamming-windowed sinc, unit DC gain (bench.py lowpass_taps)
     const int NT_ = 64;
@@ -194,15 +201,16 @@ int main(int argc, char **argv)
     CK(hipEventRecord(ev_pre[0], s0)); CK(hipEventRecord(ev_pre[1], s1));
     auto issue = [&](const Variant &v, int i) {
         const int grid = v.grid ? v.grid : cap;
-        const int lane = (v.mode >= 2 && (i & 1)) ? 1 : 0;
-        hipStream_t s = lane ? s1 : s0;
+        const int nq = v.mode == 4 ? 3 : v.mode == 5 ? 4 : v.mode == 6 ? 6 : (v.mode >= 2 ? 2 : 1);
+        const int lane = i % nq;
+        hipStream_t s = sx[lane];
         if (v.mode == 3) {       // aeth_runtime.hip: ctx_fir_lane -- wait for the other lane's history, record this lane's
             CK(hipStreamWaitEvent(s, ev_pre[1 - lane], 0));
             CK(hipEventRecord(ev_pre[lane], s));
         }
         launch(v.var, args_for(i % NBUF), grid, s, v.mode == 1);
     };
-    auto sync_all = [&] { CK(hipStreamSynchronize(s0)); CK(hipStreamSynchronize(s1)); };
+    auto sync_all = [&] { for (int i = 0; i < 6; i++) CK(hipStreamSynchronize(sx[i])); };
 
     // correctness: variant 0 against an f64 direct convolution on sampled outputs, every variant against variant 0
     std::vector<aeth_cf32> ref(NS), got(NS);
