@@ -217,6 +217,8 @@ int aeth_fft_mul_ifft_demod(aeth_fft *plan, const aeth_cf32 *frames, size_t n_to
     a.s_bwd = aeth_scale_factor(kind_bwd, plan->len, x_bwd);
     a.bits = bits_out; a.bps = bps; a.demod_compat = compat;
     for (int i = 0; i < (bps == 1 ? 2 : 4); i++) { cf t = {tb[i].re, tb[i].im}; a.tab[i] = t; }
+    // demod_naive scans 2 * bps candidates (modulation.rs:135): all four for QPSK
+    a.demod_sep = bps == 2 && tb[0].re == tb[2].re && tb[1].re == tb[3].re && tb[0].im == tb[1].im && tb[2].im == tb[3].im;
     return dispatch_fmi(plan->ctx, plan->len, a);
 }
 

@@ -37,6 +37,8 @@ struct FmiArgs {
     unsigned char *bits = nullptr;    // n * bps bytes, one per bit
     cf tab[4] = {};                   // BPSK / QPSK symbol table
     int bps = 0, demod_compat = 0;
+    int demod_sep = 0;                // QPSK table of the form {(a,c), (b,c), (a,d), (b,d)} (the generic one is): the four
+                                      // distances share their squared terms -- same rounded values, half the arithmetic
 };
 
 // Kernel variants (template parameter VAR, a bit set).  0 is the round-1 kernel.
@@ -63,6 +65,13 @@ enum : int {
     V_NOLDS = 128,  // diagnosis only (wrong output): no LDS exchanges at all
     V_NOBAR = 64,   // diagnosis only (wrong output): LDS exchanges without workgroup barriers
 };
+
+// What libaether_hip.so may instantiate; everything else is measurement / diagnosis and builds only where
+// AETH_FIR_LAB is defined non-zero before this header is included (tools/fir_lab.hip)
+constexpr int V_PRODUCT_MASK = V_PRIO | V_XOR | V_SPREAD | V_DECIM | V_DEMOD;
+#ifndef AETH_FIR_LAB
+#define AETH_FIR_LAB 0
+#endif
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -201,14 +210,27 @@ __device__ __forceinline__ void demod_block(const cf (&w)[C::P], const FmiArgs &
         const cf v = SCALED ? cscale_k(w[m], ss) : w[m];
         unsigned best = 0;
         float bd = 0.f;
+        if (a.demod_sep) {
+            // d_c = rn(rn((x - t_c.x)^2) + rn((y - t_c.y)^2)) with t_0.x == t_2.x, t_1.x == t_3.x, t_0.y == t_1.y, t_2.y == t_3.y:
+            // the four sums are built from four squares instead of eight -- bit for bit the values of the loop below
+            const float dx0 = v.x - a.tab[0].x, dx1 = v.x - a.tab[1].x, dy0 = v.y - a.tab[0].y, dy1 = v.y - a.tab[2].y;
+            float px0 = dx0 * dx0, px1 = dx1 * dx1, py0 = dy0 * dy0, py1 = dy1 * dy1;
+            asm volatile("" : "+v"(px0), "+v"(px1), "+v"(py0), "+v"(py1));
+            const float d0 = px0 + py0, d1 = px1 + py0, d2 = px0 + py1, d3 = px1 + py1;
+            bd = d0;
+            if (!(bd <= d1)) { best = 1u; bd = d1; }                         // min_by: aeth_modulation.hip, nearest()
+            if (!(bd <= d2)) { best = 2u; bd = d2; }
+            if (!(bd <= d3)) { best = 3u; bd = d3; }
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (c < ncand) {
-                const float dr = v.x - a.tab[c].x, di = v.y - a.tab[c].y;
-                float p0 = dr * dr, p1 = di * di;
-                asm volatile("" : "+v"(p0), "+v"(p1));
-                const float d = p0 + p1;
-                if (c == 0 || !(bd <= d)) { best = (unsigned)c; bd = d; }     // min_by: aeth_modulation.hip, nearest()
+            for (int c = 0; c < 4; c++) {
+                if (c < ncand) {
+                    const float dr = v.x - a.tab[c].x, di = v.y - a.tab[c].y;
+                    float p0 = dr * dr, p1 = di * di;
+                    asm volatile("" : "+v"(p0), "+v"(p1));
+                    const float d = p0 + p1;
+                    if (c == 0 || !(bd <= d)) { best = (unsigned)c; bd = d; }     // min_by: aeth_modulation.hip, nearest()
+                }
             }
         }
         if (e >= a.ov && o < a.n && e < a.frame_n) {
@@ -334,6 +356,7 @@ __device__ __forceinline__ void transform_block(cf (&w)[C::P], const cf (&tw)[C:
 template <class C, bool SCALED, int MINW, bool NT, bool BLU, int VAR = 0>
 __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
 {
+    static_assert(AETH_FIR_LAB || (VAR & ~V_PRODUCT_MASK) == 0, "lab-only kernel variant in a product build");
     __shared__ cf lds_all[C::LDS_TOTAL];
     // F == 1: the whole workgroup is one frame, so the block index stays provably wave-uniform
     const int tid = (C::F == 1) ? (int)threadIdx.x : (int)(threadIdx.x % C::T);

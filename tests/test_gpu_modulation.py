@@ -246,6 +246,28 @@ def test_correlate_then_demod_in_one_call(ctx, oracle, n, frames, bps):
     assert (mod.correlate_demod(f, tx, sig, Scale.SN, Scale.SN).to_host() == mod.demod_naive(ref2).to_host()).all()
 
 
+def test_correlate_demod_with_a_custom_table(ctx):
+    """The fused chain's decisions for a QPSK table that is NOT of the separable form {(a,c), (b,c), (a,d), (b,d)} (a
+    rotated constellation: the shared-squares path must not be taken) and for a separable one with unequal levels, with
+    values on the decision boundaries, NaN and Inf among the samples: same bits as mul_chain + demod_naive."""
+    n, frames = 2048, 8
+    f = HipFft(ctx, n, max_batch=frames)
+    x = rand_c64(5, n * frames, scale=1.5)
+    x[::97] = 0                                                    # exact ties between all four candidates
+    x[5] = complex(np.nan, 1.0); x[6] = complex(np.inf, -np.inf)
+    ident = np.zeros(n, np.complex64); ident[:] = 1.0 / n          # sig = 1/N everywhere: the chain returns the frame itself ...
+    for tab in (np.array([1 + 0j, 0 + 1j, 0 - 1j, -1 + 0j], np.complex64),                     # rotated by 45 degrees: not separable
+                np.array([2 + 1j, -0.5 + 1j, 2 - 3j, -0.5 - 3j], np.complex64)):               # separable, unequal levels
+        mod = modulation.table(ctx, tab)
+        for sig in (ctx.vec(rand_c64(9, n)), ctx.vec(ident)):
+            tx, ref = ctx.vec(x), ctx.vec(x)
+            f.mul_chain(ref, sig)
+            for compat in (True, False):
+                want = mod.demod_naive(ref, compat=compat).to_host()
+                got = mod.correlate_demod(f, tx, sig, compat=compat).to_host()
+                assert (got == want).all()
+
+
 def test_c4_chain(ctx, oracle):
     """QPSK mod -> AWGN (power 0.01, examples/modem.rs:25) -> per 2048-frame rfft * conj-reference
     -> rifft -> hard demod.  Correlating against a unit impulse reference leaves the frame

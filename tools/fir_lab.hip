@@ -7,6 +7,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -Iaether_primitives_amd/csrc tools/fir_lab.hip \
 //         -o tools/bin/fir_lab -Laether_primitives_amd/lib -laether_hip -Wl,-rpath,'$ORIGIN/../../aether_primitives_amd/lib'
 // run:  tools/bin/fir_lab [steps=300] [rounds=5] [name ...]      (no names: every variant)
+#define AETH_FIR_LAB 1        // the diagnosis / measurement variants of fmi_kernel (aeth_fir_kernel.h)
 #include "aeth_fft_plan.h"
 #include "aeth_fir_kernel.h"
 
