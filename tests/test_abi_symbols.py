@@ -76,3 +76,12 @@ def test_errors_do_not_need_a_gpu():
     assert lib.aeth_scale_factor(0, 4, 9.0) == 1.0                    # None
     with pytest.raises(_lib.AetherError):
         _lib.check(lib.aeth_fft_exec(None, None, 0, None, 0, 1, 0, 0.0))
+    # the pinned pool and the explicit registration validate their arguments before touching the runtime
+    p = C.c_void_p()
+    assert lib.aeth_pool_create(None, 4096, 1, 0, C.byref(p)) == _lib.E_ARG and not p.value
+    assert lib.aeth_pool_take(None, C.byref(p)) == _lib.E_ARG
+    assert lib.aeth_pool_len(None) == 0 and lib.aeth_pool_cap(None) == 0 and lib.aeth_pool_destroy(None) == _lib.OK
+    assert lib.aeth_host_register(None, None, 0) == _lib.E_ARG
+    buf = (C.c_char * 64)()
+    assert lib.aeth_host_is_pinned(buf, 64) == 0
+    assert lib.aeth_downsample_release(None, None, 8, None, 4, 8, 0) == _lib.E_ARG
