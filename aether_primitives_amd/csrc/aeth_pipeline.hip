@@ -233,7 +233,7 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
     std::unique_ptr<std::atomic<int>[]> in_pending(new std::atomic<int>[nchunks]), out_pending(new std::atomic<int>[nchunks]);
     for (size_t k = 0; k < nchunks; k++) { in_pending[k].store(0); out_pending[k].store(0); }
     std::vector<double> t_in(stage_in ? nchunks : 0, 0.0), t_out(stage_out ? nchunks : 0, 0.0);
-    double act_in = 0, act_out = 0;
+    double act_in = 0, act_out = 0, last_in = 0, last_out = 0;
     size_t next_in = 0, next_sub = 0, next_out = 0, fin_in = 0, fin_out = 0;
     auto geom = [&](size_t k, size_t &o0, size_t &cnt, size_t &h) {
         o0 = k * chunk; cnt = (n - o0 < chunk) ? n - o0 : chunk; h = (o0 >= nh) ? nh : o0;     // h: history samples the source holds
@@ -258,7 +258,12 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
                 next_in++; progress = true;
             }
         }
-        while (stage_in && fin_in < next_in && in_pending[fin_in].load(std::memory_order_acquire) == 0) { act_in += now_s() - t_in[fin_in]; fin_in++; progress = true; }
+        // busy time of a host stage = the union of its chunks' [hand-over, completion] intervals (several can be queued)
+        while (stage_in && fin_in < next_in && in_pending[fin_in].load(std::memory_order_acquire) == 0) {
+            const double t = now_s(), from = t_in[fin_in] > last_in ? t_in[fin_in] : last_in;
+            if (t > from) act_in += t - from;
+            last_in = t; fin_in++; progress = true;
+        }
         // ---- device stages of chunk k: its input is in place and its pinned output element has been emptied
         if (next_sub < nchunks) {
             const size_t k = next_sub; const int s = (int)(k % kPipeSlots);
@@ -314,7 +319,11 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
                 next_out++; progress = true;
             } else if (q != hipErrorNotReady) { fail(q, "hipEventQuery"); break; }
         }
-        while (stage_out && fin_out < next_out && out_pending[fin_out].load(std::memory_order_acquire) == 0) { act_out += now_s() - t_out[fin_out]; fin_out++; progress = true; }
+        while (stage_out && fin_out < next_out && out_pending[fin_out].load(std::memory_order_acquire) == 0) {
+            const double t = now_s(), from = t_out[fin_out] > last_out ? t_out[fin_out] : last_out;
+            if (t > from) act_out += t - from;
+            last_out = t; fin_out++; progress = true;
+        }
         // nothing moved: a chunk takes hundreds of microseconds, so back off instead of hammering the runtime with
         // event queries (its completion handling shares locks with them)
         if (progress) idle = 0;
