@@ -120,20 +120,22 @@ int pipe_prepare(aeth_ctx *ctx, size_t din_bytes, size_t dout_bytes, int nslots)
         if (!p->ran[s]) AETH_HIP(hipEventCreateWithFlags(&p->ran[s], hipEventDisableTiming));
         if (!p->down[s]) AETH_HIP(hipEventCreateWithFlags(&p->down[s], hipEventDisableTiming));
     }
-    if (p->din_bytes < din_bytes || p->dout_bytes < dout_bytes) {
+    // every slot has the size on record (the largest asked for so far): a slot allocated later, for a run with more
+    // chunks, must not be smaller than the ones a previous run sized
+    const size_t want_in = p->din_bytes > din_bytes ? p->din_bytes : din_bytes;
+    const size_t want_out = p->dout_bytes > dout_bytes ? p->dout_bytes : dout_bytes;
+    if (p->din_bytes < want_in || p->dout_bytes < want_out) {
         for (int i = 0; i < 3; i++) AETH_HIP(hipStreamSynchronize(p->stream[i]));
         for (int s = 0; s < kPipeSlots; s++) {
             if (p->din[s]) { AETH_HIP(hipFree(p->din[s])); p->din[s] = nullptr; }
             if (p->dout[s]) { AETH_HIP(hipFree(p->dout[s])); p->dout[s] = nullptr; }
         }
-        p->din_bytes = p->dout_bytes = 0;
+        p->din_bytes = want_in; p->dout_bytes = want_out;
     }
     for (int s = 0; s < nslots; s++) {
-        if (!p->din[s]) AETH_HIP(hipMalloc((void **)&p->din[s], din_bytes));
-        if (!p->dout[s]) AETH_HIP(hipMalloc((void **)&p->dout[s], dout_bytes));
+        if (!p->din[s]) AETH_HIP(hipMalloc((void **)&p->din[s], p->din_bytes));
+        if (!p->dout[s]) AETH_HIP(hipMalloc((void **)&p->dout[s], p->dout_bytes));
     }
-    if (p->din_bytes < din_bytes) p->din_bytes = din_bytes;
-    if (p->dout_bytes < dout_bytes) p->dout_bytes = dout_bytes;
     return AETH_OK;
 }
 

@@ -100,6 +100,20 @@ def test_stream_from_pool_elements_is_direct_and_bit_identical(ctx, n):
     p.close()
 
 
+def test_pipeline_slots_keep_the_size_on_record():
+    """The pipeline's device slots and staging elements live in the context between runs.  A run with ONE large chunk,
+    then one with three small chunks (two more slots get allocated), then one with three chunks in between: every slot
+    has to have the largest size asked for so far, not the size of the run that first needed it."""
+    c = ap.Context(0)
+    f = ap.Fir(c, rand_c64(1, 64, scale=0.2), 2048)
+    hop = f.hop
+    for n, chunk in ((hop * 40, hop * 40), (hop * 15, hop * 5), (hop * 60, hop * 20), (hop * 60 + 7, hop * 20), (hop * 200, hop * 50)):
+        x = rand_c64(n, n)
+        y, st = f.filter_stream(x, chunk=chunk)
+        assert st["chunks"] == -(-n // chunk) and bits_equal(y, f.filter(x)), (n, chunk)
+    c.close()
+
+
 def test_stream_of_nothing_reports_nothing(ctx):
     f = ap.Fir(ctx, rand_c64(1, 64), 2048)
     y, st = f.filter_stream(np.zeros(0, np.complex64), report=True)      # no ZeroDivisionError: no rates for an empty run
