@@ -26,7 +26,7 @@
 #include <vector>
 
 struct aeth_pool {
-    aeth_ctx *ctx = nullptr;
+    int device = 0;                     // of the context it was made on (kept by value: a pool may outlive its context)
     size_t elem_bytes = 0;
     int flags = 0;
     std::mutex mu;                      // Pool<T> = Arc<Mutex<PoolInner<T>>> (pool.rs:71-73)
@@ -57,7 +57,7 @@ size_t page_size()
 
 int pool_make_locked(aeth_pool *p, void **out)          // the `maker` (pool.rs:46,117): one pinned element
 {
-    aeth::DeviceGuard g(p->ctx->device);
+    aeth::DeviceGuard g(p->device);
     void *h = nullptr;
     AETH_HIP(hipHostMalloc(&h, p->elem_bytes, hipHostMallocPortable));
     aeth::pinned_add(h, p->elem_bytes, aeth::PIN_POOL);
@@ -98,7 +98,7 @@ int pool_destroy_forced(aeth_pool *p)
     if (!p) return AETH_OK;
     int rc = AETH_OK;
     {
-        aeth::DeviceGuard g(p->ctx->device);
+        aeth::DeviceGuard g(p->device);
         std::lock_guard<std::mutex> l(p->mu);
         for (void *h : p->owned) {
             pinned_remove(h);
@@ -124,7 +124,7 @@ int aeth_pool_create(aeth_ctx *ctx, size_t elem_bytes, size_t initial_len, int f
     AETH_REQUIRE((flags & ~AETH_POOL_ZERO_ON_RETURN) == 0, AETH_E_ARG, "unknown pool flags %d", flags);
     aeth_pool *p = new (std::nothrow) aeth_pool();
     AETH_REQUIRE(p, AETH_E_NOMEM, "out of host memory");
-    p->ctx = ctx; p->elem_bytes = elem_bytes; p->flags = flags;
+    p->device = ctx->device; p->elem_bytes = elem_bytes; p->flags = flags;
     for (size_t i = 0; i < initial_len; i++) {
         void *h = nullptr;
         const int rc = pool_make_locked(p, &h);
