@@ -73,6 +73,15 @@ constexpr int V_PRODUCT_MASK = V_PRIO | V_XOR | V_SPREAD | V_DECIM | V_DEMOD;
 #define AETH_FIR_LAB 0
 #endif
 
+// cache-policy bits of the streamed accesses (aux operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1);
+// macros so that tools/fir_lab can be built with other choices
+#ifndef AETH_FIR_LOAD_AUX
+#define AETH_FIR_LOAD_AUX 2
+#endif
+#ifndef AETH_FIR_STORE_AUX
+#define AETH_FIR_STORE_AUX 18
+#endif
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // Stream accesses carry the non-temporal hint (aux bit 1) when the launch moves more than the cache holds: a
@@ -101,7 +110,7 @@ __device__ __forceinline__ void load_window(cf (&x)[C::P], const FmiArgs &a, lon
             auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
             for (int m = 0; m < C::P; m++)
-                x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
+                x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? AETH_FIR_LOAD_AUX : 0));
             // (the window's oldest ov-nhist samples are zeroed when the window is consumed: doing it
             // here would put a wait for the load right behind its issue)
             return;
@@ -156,7 +165,7 @@ __device__ __forceinline__ void load_window_srd(cf (&x)[C::P], const FmiArgs &a,
     auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
     for (int m = 0; m < C::P; m++)
-        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
+        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? AETH_FIR_LOAD_AUX : 0));
 }
 
 // the same, slots [M0, M1) only (V_SPREAD: the window arrives in four instalments)
@@ -170,7 +179,7 @@ __device__ __forceinline__ void load_window_srd_part(cf (&x)[C::P], const FmiArg
     auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
 #pragma unroll
     for (int m = M0; m < M1; m++)
-        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? 2 : 0));
+        x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? AETH_FIR_LOAD_AUX : 0));
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -266,7 +275,7 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
             const bool keep = e >= a.ov && q * a.dec.d == o && (long long)o < a.n;
             const int off = keep ? (int)(q - q0) * 8 : 0x7ffffff0;
             cf v = SCALED ? cscale_k(w[m], ss) : w[m];
-            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 18 : 0);
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? AETH_FIR_STORE_AUX : 0);
         }
     } else if constexpr (C::F == 1) {
         long long left = a.n - base;
@@ -281,7 +290,7 @@ __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &
             const int e = tid + m * C::T;
             const int off = (e >= a.ov) ? e * 8 : 0x7ffffff0;
             cf v = SCALED ? cscale_k(w[m], ss) : w[m];
-            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? 18 : 0);   // nt + sc1: streamed stores (tools/nt_modes.hip: 6.55 vs 6.43 TB/s for nt alone)
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v), rs, off, 0, NT ? AETH_FIR_STORE_AUX : 0);   // nt + sc1: streamed stores (tools/nt_modes.hip: 6.55 vs 6.43 TB/s for nt alone)
         }
     } else {
 #pragma unroll
