@@ -195,7 +195,7 @@ int launch_pow2(const aeth_fft *plan, const float2 *in, float2 *out, size_t batc
         size_t cap2 = (size_t)ctx->num_cus * (512 / C::WG);
         int grid2 = (int)(batch < cap2 ? batch : cap2);
         if (grid2 < 1) grid2 = 1;
-        if (!aeth::tuning_int("AETH_FFT_NOSTREAM", 0)) {
+        if (!aeth::lab_int("AETH_FFT_NOSTREAM", 0)) {
 #define AETH_FFT_STREAM(SS, NN) hipLaunchKernelGGL((fft_pow2_stream_kernel<C, SS, NN>), dim3(grid2), dim3(C::WG), 0, aeth::ctx_stream(ctx), (const cf *)in, (cf *)out, (const cf *)plan->tw_lane_dev, batch, scale, mirror)
             if (sign > 0) { if (nt) AETH_FFT_STREAM(+1, true); else AETH_FFT_STREAM(+1, false); }
             else          { if (nt) AETH_FFT_STREAM(-1, true); else AETH_FFT_STREAM(-1, false); }
@@ -549,7 +549,7 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
     auto big_radix = [](int r) { return r == 11 || r == 13 || r == 17 || r == 19 || r == 23; };
     bool bigr = false;
     for (int i = 0; i < d.nfac; i++) bigr = bigr || big_radix(d.pass[i].R);
-    bigr = bigr && aeth::tuning_int("AETH_MIXED_BIGR", 1) != 0;
+    bigr = bigr && aeth::lab_int("AETH_MIXED_BIGR", 1) != 0;
     d.stage = (d.nfac == 1 || (d.nfac > 0 && !small_radix(d.pass[0].R) && !(bigr && big_radix(d.pass[0].R)))) ? 1 : 0;
     // Lanes per frame.  These kernels are latency-bound (a chain of short passes with a barrier each), so
     // what counts is how many frames a CU has in flight, and the number of workgroups per CU is capped by
@@ -562,9 +562,9 @@ int launch_mixed(const aeth_fft *plan, const float2 *in, float2 *out, size_t bat
     // one LDS image per frame (passes exchange in place) whenever every radix has a register form
     bool all_small = d.nfac > 0;
     for (int i = 0; i < d.nfac; i++) all_small = all_small && small_radix(d.pass[i].R);
-    const bool inplace = all_small && aeth::tuning_int("AETH_MIXED_INPLACE", 1) != 0;
+    const bool inplace = all_small && aeth::lab_int("AETH_MIXED_INPLACE", 1) != 0;
     const size_t frame_bytes = (size_t)((inplace && plan->len > 4096) ? 1 : 2) * plan->len * sizeof(cf);
-    int tpf = aeth::tuning_int("AETH_MIXED_TPF", 0);
+    int tpf = aeth::lab_int("AETH_MIXED_TPF", 0);
     if (tpf < 1 || tpf > kMixedWG || (tpf & (tpf - 1))) {
         int widest = 1;
         while (widest < need && widest < kMixedWG) widest <<= 1;
@@ -639,7 +639,7 @@ bool split_fourstep_mixed(size_t len, size_t *n1, size_t *n2)
     // transform is the bulk of the three launches and the rows from 8192 points down run at 4.3-5.9 TB/s where the
     // largest ones reach 2.9-4.1, so the smallest factor that brings the rest under that length goes first
     // (40960 as 5 x 8192 instead of 2 x 20480)
-    const size_t pref = (size_t)aeth::tuning_int("AETH_4SM_PREF_M", 8192);
+    const size_t pref = (size_t)aeth::lab_int("AETH_4SM_PREF_M", 8192);
     for (int pass = 0; pass < 2; pass++)
         for (size_t r = 2; r <= 16; r++) {
             if (!aeth::fourstep_small_factor(r) || len % r) continue;
@@ -757,15 +757,15 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
         p->algo = aeth::FFT_ALGO_MIXED;      // zero passes: copy + scale
         p->factors.clear();
         p->algo_name = "identity";
-    } else if (is_pow2(len) && (len <= 4096 || (len == 8192 && (!aeth::fft_ragged_supported(len) || aeth::tuning_int("AETH_FFT_NORAGGED", 0))))) {
+    } else if (is_pow2(len) && (len <= 4096 || (len == 8192 && (!aeth::fft_ragged_supported(len) || aeth::lab_int("AETH_FFT_NORAGGED", 0))))) {
         // 8192 itself has a row in the ragged table (256 lanes x 32 points, radices 32 32 8, unpadded image: 102 us
         // per 32 Mi samples against 124 us for the 512-lane x 16-point kernel here, which spills at two waves per SIMD)
         p->algo = aeth::FFT_ALGO_POW2;
         p->algo_name = "stockham_pow2";
-    } else if (aeth::fft_ragged_supported(len) && !aeth::tuning_int("AETH_FFT_NORAGGED", 0)) {
+    } else if (aeth::fft_ragged_supported(len) && !aeth::lab_int("AETH_FFT_NORAGGED", 0)) {
         p->algo = aeth::FFT_ALGO_RAGGED;
         p->algo_name = "stockham_mixed_ragged";
-    } else if (2 * len - 1 <= 4096 && largest_prime_factor(len) >= (size_t)aeth::tuning_int("AETH_FFT_PRIME_BLU_MIN", 17) && aeth::tuning_int("AETH_FFT_PRIME_BLU", 1)) {
+    } else if (2 * len - 1 <= 4096 && largest_prime_factor(len) >= (size_t)aeth::lab_int("AETH_FFT_PRIME_BLU_MIN", 17) && aeth::lab_int("AETH_FFT_PRIME_BLU", 1)) {
         // a prime factor from 17 up and a chirp-z convolution that fits the one-launch kernel (M <= 4096): 1.4-2.6 TB/s
         // against 0.05-0.7 TB/s through the generic O(r^2) pass of the LDS kernel and 0.4-1.0 TB/s through
         // fourstep_mixed (tools/prime_route.py: 17 ... 2047, x1.1 ... x50)
@@ -779,7 +779,7 @@ int aeth_fft_create(aeth_ctx *ctx, size_t len, size_t max_batch, aeth_fft **out)
         p->algo = aeth::FFT_ALGO_FOURSTEP;
         p->algo_name = "fourstep_pow2";
         rc = aeth::fft_plan_fourstep(p);
-    } else if (!aeth::tuning_int("AETH_FFT_NO4SMIXED", 0) && split_fourstep_mixed(len, &p->n1, &p->n2)) {
+    } else if (!aeth::lab_int("AETH_FFT_NO4SMIXED", 0) && split_fourstep_mixed(len, &p->n1, &p->n2)) {
         p->algo = aeth::FFT_ALGO_FOURSTEP_MIXED;
         p->algo_name = "fourstep_mixed";
         rc = aeth::fft_plan_fourstep_mixed(p);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__((col_group_of<C0, GW, MAXL>()) * C0::T) void fourst
     //   W_N^(n2*tid) * (W_N^(T*n2))^m.
     // Three table reads (a, b, b^4) and short product chains (depth <= 5) replace one
     // scattered 8-byte gather per element, which costs more than the arithmetic here.
-    if (twN) {
+    {
         const cf a = twN[(size_t)n2 * tid];
         const cf b1 = twN[(size_t)n2 * C::T];
         const cf b4 = twN[(size_t)n2 * C::T * 4];
@@ -164,10 +164,10 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_tot
     const bool nt = aeth::streams_past_cache(plan->len * batch_total * sizeof(float2) * 4 / 3);   // from 96 MiB: x, a and X together pass the cache
     // 32 adjacent columns per workgroup (256-byte segments) where lanes and LDS allow (n1 <= 256): 512 x 65536 runs in
     // 169 us against 177 us with 16 (tools/tune_4step.py, AETH_4S_COLG), no difference on small batches
-    const bool wide = aeth::tuning_int("AETH_4S_COLG", 32) >= 32 && col_group_of<C, 32>() == 32 && plan->n2 % 32 == 0;
+    const bool wide = aeth::lab_int("AETH_4S_COLG", 32) >= 32 && col_group_of<C, 32>() == 32 && plan->n2 % 32 == 0;
     // columns of 1024 points and more (64+ lanes each): 16 of them make a 1024-lane workgroup, which caps the kernel at
     // 128 VGPRs and spills 22-28 of them; 8 columns (512 lanes, 256 VGPRs, 64-byte row segments) is the alternative
-    const bool half = !wide && C::T >= 64 && aeth::tuning_int("AETH_4S_MAXL", 1024) <= 512;
+    const bool half = !wide && C::T >= 64 && aeth::lab_int("AETH_4S_MAXL", 1024) <= 512;
     const int G = wide ? 32 : half ? col_group_of<C, 16, 512>() : col_group_of<C, 16>();
     const size_t grid = batch * (plan->n2 / G);
     auto kern = wide ? (nt ? fourstep_cols<C, S, true, 32> : fourstep_cols<C, S, false, 32>)
@@ -175,7 +175,7 @@ int launch_cols(aeth_fft *plan, const float2 *in, size_t batch, size_t batch_tot
                        : (nt ? fourstep_cols<C, S, true, 16> : fourstep_cols<C, S, false, 16>);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * C::T), 0, stream,
                        (const cf *)in, (cf *)(plan->work_dev + work_off), (const cf *)plan->sub1->tw_lane_dev,
-                       aeth::tuning_int("AETH_4S_NOTW", 0) ? nullptr : (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
+                       (const cf *)plan->tw_dev, (int)plan->n2, plan->len);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
@@ -402,9 +402,9 @@ int fft_plan_fourstep(aeth_fft *plan)
     if (k >= 16 && k <= 18) plan->n1 = 256;
     else if (k >= 19 && k <= 23) plan->n1 = (size_t)1 << (k - 11);
     // deep form (fft_run_fourstep): n1 <= 256 columns over rows of 65536 points that are four-step transforms themselves
-    const int deep_from = aeth::tuning_int("AETH_4S_DEEP_FROM", 23);
+    const int deep_from = aeth::lab_int("AETH_4S_DEEP_FROM", 23);
     if (k >= deep_from && k >= 21) plan->n1 = (size_t)1 << (k - 16);
-    const int n1log = aeth::tuning_int("AETH_4S_N1LOG", 0);
+    const int n1log = aeth::lab_int("AETH_4S_N1LOG", 0);
     if (n1log >= 4 && n1log < k && k - n1log <= 12) plan->n1 = (size_t)1 << n1log;
     plan->n2 = plan->len / plan->n1;
     if (plan->n1 < 16 || (plan->n2 > 4096 && plan->n2 != 65536)) return set_error(AETH_E_UNSUPPORTED, "fourstep_pow2: length %zu", plan->len);
@@ -421,53 +421,12 @@ int fft_run_fourstep(aeth_fft *plan, const float2 *in, float2 *out, size_t batch
     // with groups of 128 / 64 / 32 / 16 MiB.  Each of the two launches already streams at copy speed (537 MB in
     // 88 us) and part of the intermediate is served from the cache as it is; more launches only add their gaps.
     // The knob stays for the tuning tool: 0 = one group (default).
-    const size_t gmib = (size_t)aeth::tuning_int("AETH_4S_GROUP_MIB", 0);
+    const size_t gmib = (size_t)aeth::lab_int("AETH_4S_GROUP_MIB", 0);
     size_t gf = gmib ? gmib * ((size_t)1 << 20) / (plan->len * sizeof(float2)) : batch;
     if (gf < 1) gf = 1;
     if (gf > batch) gf = batch;
-    // Lab shape (round 3, AETH_4S_PARTS=2; measured, not kept -- profiles/r03_c5.json): frame groups dealt to TWO HIP
-    // streams, each running its groups' step A and step B back to back, so that one group's step B runs beside the
-    // other's step A (the fill of one launch under the drain of another, and a read-strided kernel beside a
-    // write-strided one); with AETH_4S_GROUP_MIB the two work-buffer regions stay cache-sized.
-    if (aeth::tuning_int("AETH_4S_PARTS", 1) == 2 && batch >= 2 && plan->n2 <= 4096) {
-        if (!gmib) gf = (batch + 1) / 2;
-        int rc = ensure_work(plan, plan->len * gf * 2);
-        if (rc) return rc;
-        aeth::DeviceGuard dg(plan->ctx->device);
-        static thread_local hipStream_t lab_stream = nullptr;
-        static thread_local hipEvent_t lab_ev[2] = {nullptr, nullptr};
-        if (!lab_stream) {
-            AETH_HIP(hipStreamCreateWithFlags(&lab_stream, hipStreamNonBlocking));
-            AETH_HIP(hipEventCreateWithFlags(&lab_ev[0], hipEventDisableTiming));
-            AETH_HIP(hipEventCreateWithFlags(&lab_ev[1], hipEventDisableTiming));
-        }
-        hipStream_t st[2] = {aeth::ctx_stream(plan->ctx), lab_stream};
-        AETH_HIP(hipEventRecord(lab_ev[0], st[0]));
-        AETH_HIP(hipStreamWaitEvent(st[1], lab_ev[0], 0));               // the second stream starts behind the context's work
-        size_t gi = 0;
-        for (size_t g0 = 0; g0 < batch; g0 += gf, gi++) {
-            const size_t cnt = batch - g0 < gf ? batch - g0 : gf;
-            const float2 *gin = in + g0 * plan->len;
-            float2 *gout = out + g0 * plan->len;
-            hipStream_t s = st[gi & 1];
-            const size_t off = (gi & 1) * gf * plan->len;
-#define AETH_BODY(NN)                                                                                   \
-    return sign > 0 ? launch_cols<typename CfgFor<NN>::type, +1>(plan, gin, cnt, batch, s, off)          \
-                    : launch_cols<typename CfgFor<NN>::type, -1>(plan, gin, cnt, batch, s, off)
-            auto cols = [&]() -> int { AETH_POW2_SWITCH(plan->n1, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n1")) };
-#undef AETH_BODY
-#define AETH_BODY(NN)                                                                                   \
-    return sign > 0 ? launch_rows<typename CfgFor<NN>::type, +1>(plan, gout, cnt, scale, batch, s, off)  \
-                    : launch_rows<typename CfgFor<NN>::type, -1>(plan, gout, cnt, scale, batch, s, off)
-            auto rows = [&]() -> int { AETH_POW2_SWITCH(plan->n2, AETH_BODY, return set_error(AETH_E_UNSUPPORTED, "n2")) };
-#undef AETH_BODY
-            rc = cols(); if (rc) return rc;
-            rc = rows(); if (rc) return rc;
-        }
-        AETH_HIP(hipEventRecord(lab_ev[1], st[1]));
-        AETH_HIP(hipStreamWaitEvent(st[0], lab_ev[1], 0));               // and the context's stream continues behind it
-        return AETH_OK;
-    }
+    // (round 3 also measured frame halves on two HIP streams -- one half's step B beside the other's step A: 181.9 us
+    // against 170.6 for 512 frames, 46.8 against 30.7 for 64, profiles/r03_c5.json; that shape is not in the library)
     int rc = ensure_work(plan, plan->len * gf);
     if (rc) return rc;
     for (size_t g0 = 0; g0 < batch; g0 += gf) {
@@ -567,7 +526,7 @@ int fft_plan_bluestein(aeth_fft *plan)
     // Past the one-launch kernel (M <= 4096) the convolution length need not be a power of two: the nearest length at
     // or above 2N-1 that one register-resident launch transforms (N = 4099: 8640 = 2^6 3^3 5 instead of 16384, half the
     // bytes through each of the five launches).
-    if (M > 4096 && aeth::tuning_int("AETH_BLU_ANY_M", 1)) {
+    if (M > 4096 && aeth::lab_int("AETH_BLU_ANY_M", 1)) {
         const size_t table_top = 20480;                    // the largest length the ragged table holds
         for (size_t m = 2 * N - 1; m < M && m <= table_top; m++)
             if (aeth::fft_ragged_supported(m)) { M = m; break; }

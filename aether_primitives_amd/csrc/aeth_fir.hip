@@ -56,10 +56,6 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;
     FmiArgs b = a;
-    b.dbg = aeth::tuning_int("AETH_FIR_DBG", 0);            // 4: gather twiddles from the master table
-    if (b.dbg & 4) b.twL = nullptr;
-    const int g = aeth::tuning_int("AETH_FIR_GRID", 0);
-    if (g > 0 && g < grid) grid = g;
     if (b.frame_n == 0) b.frame_n = C::N;
     const bool nt = aeth::streams_past_cache(2 * (size_t)a.n * sizeof(float2));
     if constexpr (SCALED) {
@@ -77,8 +73,17 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     constexpr int VAR = (C::F == 1) ? (V_PRIO | (C::N == 2048 ? V_XOR : 0)) : 0;
     if constexpr (C::F == 1) {
         if (b.bits) {                                       // hard demodulation instead of the sample store
-            if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR | V_DEMOD>), dim3(grid), dim3(C::WG), 0, stream, b);
-            else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false, VAR | V_DEMOD>), dim3(grid), dim3(C::WG), 0, stream, b);
+            // the decision's mode is a template parameter (aeth_fir_kernel.h: demod_block): BPSK, QPSK with a
+            // separable table, QPSK with any other table -- nothing about it is tested per sample
+#define AETH_DM(DMV)                                                                                                                \
+            do {                                                                                                                    \
+                if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR | V_DEMOD | (DMV)>), dim3(grid), dim3(C::WG), 0, stream, b); \
+                else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false, VAR | V_DEMOD | (DMV)>), dim3(grid), dim3(C::WG), 0, stream, b);   \
+            } while (0)
+            if (b.bps == 1) AETH_DM(V_DM_BPSK);
+            else if (b.demod_sep) AETH_DM(0);
+            else AETH_DM(V_DM_QGEN);
+#undef AETH_DM
             AETH_HIP(hipGetLastError());
             return AETH_OK;
         }
@@ -137,7 +142,6 @@ int fmi_bluestein(aeth_fft *sub, const float2 *in, float2 *out, size_t n, size_t
                   const float2 *filt, int conj, float scale)
 {
     FmiArgs a;
-    a.dbg = 0;
     a.in = (const cf *)in; a.out = (cf *)out; a.hist = nullptr; a.Hf = (const cf *)filt;
     a.twN = (const cf *)sub->tw_dev; a.twL = (const cf *)sub->tw_lane_dev;
     a.n = (long long)(n * batch); a.nblocks = (long long)batch;
@@ -171,7 +175,6 @@ int aeth_fft_mul_ifft(aeth_fft *plan, aeth_cf32 *frames, size_t n_total, size_t 
         return aeth_fft_exec(plan, frames, n_total, frames, batch, AETH_SIGN_REF_BWD, kind_bwd, x_bwd);
     }
     FmiArgs a;
-    a.dbg = 0;
     a.in = (const cf *)frames; a.out = (cf *)frames; a.hist = nullptr; a.Hf = (const cf *)sig;
     a.twN = (const cf *)plan->tw_dev; a.twL = (const cf *)plan->tw_lane_dev; a.n = (long long)n_total; a.nblocks = (long long)batch;
     a.hop = (int)plan->len; a.ov = 0; a.nhist = 0;
@@ -209,7 +212,6 @@ int aeth_fft_mul_ifft_demod(aeth_fft *plan, const aeth_cf32 *frames, size_t n_to
         return aeth_demod_naive(plan->ctx, (const aeth_cf32 *)plan->tmp_dev, n_total, bps, table, bits_out, nbits_out, compat);
     }
     FmiArgs a;
-    a.dbg = 0;
     a.in = (const cf *)frames; a.out = nullptr; a.hist = nullptr; a.Hf = (const cf *)sig;
     a.twN = (const cf *)plan->tw_dev; a.twL = (const cf *)plan->tw_lane_dev; a.n = (long long)n_total; a.nblocks = (long long)batch;
     a.hop = (int)plan->len; a.ov = 0; a.nhist = 0;
@@ -219,7 +221,15 @@ int aeth_fft_mul_ifft_demod(aeth_fft *plan, const aeth_cf32 *frames, size_t n_to
     for (int i = 0; i < (bps == 1 ? 2 : 4); i++) { cf t = {tb[i].re, tb[i].im}; a.tab[i] = t; }
     // demod_naive scans 2 * bps candidates (modulation.rs:135): all four for QPSK
     a.demod_sep = bps == 2 && tb[0].re == tb[2].re && tb[1].re == tb[3].re && tb[0].im == tb[1].im && tb[2].im == tb[3].im;
-    return dispatch_fmi(plan->ctx, plan->len, a);
+    // out of place (frames are only read), so consecutive calls on disjoint buffers can run on the context's two
+    // queues like consecutive aeth_fir_exec calls do (aeth_ctx_set_overlap): the drain of one beside the fill of the next
+    // (a reference signal that the previous chained launch may still be writing keeps this call on the in-order stream)
+    aeth_ctx *cx = plan->ctx;
+    const bool sig_busy = cx->chain_last >= 0 && (uintptr_t)sig < cx->last_out[1] && cx->last_out[0] < (uintptr_t)(sig + n_sig);
+    hipStream_t lane = sig_busy ? aeth::ctx_stream(cx)
+                                : aeth::ctx_fir_lane(cx, (uintptr_t)frames, (uintptr_t)(frames + n_total), (uintptr_t)bits_out,
+                                                     (uintptr_t)(bits_out + nbits_out));
+    return dispatch_fmi(plan->ctx, plan->len, a, lane);
 }
 
 int aeth_fir_create(aeth_ctx *ctx, const aeth_cf32 *taps, size_t ntaps, size_t fft_len, aeth_fir **out)
@@ -284,7 +294,6 @@ int aeth_fir_exec(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_
     AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out) && aeth::aligned8(hist), AETH_E_ALIGN,
                  "pointer not 8-byte aligned");
     FmiArgs a;
-    a.dbg = 0;
     a.in = (const cf *)in; a.out = (cf *)out; a.hist = (const cf *)hist; a.Hf = (const cf *)f->Hf; a.twN = (const cf *)f->fft->tw_dev; a.twL = (const cf *)f->fft->tw_lane_dev;
     a.n = (long long)n; a.hop = (int)f->hop; a.ov = (int)(f->fft_len - f->hop); a.nhist = (int)(f->ntaps - 1);
     a.nblocks = (long long)((n + f->hop - 1) / f->hop);
@@ -314,7 +323,6 @@ int aeth_fir_exec_decim(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in,
                  "decimating store: fft_len %zu (one-block-per-workgroup lengths 1024 .. 4096 only)", f->fft_len);
     AETH_REQUIRE(n < ((size_t)1 << 31), AETH_E_UNSUPPORTED, "decimating store: %zu samples (32-bit index arithmetic)", n);
     FmiArgs a;
-    a.dbg = 0;
     a.in = (const cf *)in; a.out = (cf *)out; a.hist = (const cf *)hist; a.Hf = (const cf *)f->Hf;
     a.twN = (const cf *)f->fft->tw_dev; a.twL = (const cf *)f->fft->tw_lane_dev;
     a.n = (long long)n; a.hop = (int)f->hop; a.ov = (int)(f->fft_len - f->hop); a.nhist = (int)(f->ntaps - 1);
@@ -331,7 +339,6 @@ namespace aeth {
 int fir_exec_on(aeth_fir *f, hipStream_t stream, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out)
 {
     FmiArgs a;
-    a.dbg = 0;
     a.in = (const cf *)in; a.out = (cf *)out; a.hist = (const cf *)hist; a.Hf = (const cf *)f->Hf;
     a.twN = (const cf *)f->fft->tw_dev; a.twL = (const cf *)f->fft->tw_lane_dev;
     a.n = (long long)n; a.hop = (int)f->hop; a.ov = (int)(f->fft_len - f->hop); a.nhist = (int)(f->ntaps - 1);

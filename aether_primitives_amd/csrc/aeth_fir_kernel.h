@@ -24,7 +24,6 @@ struct FmiArgs {
     long long nblocks;
     int hop, ov, nhist;
     float s_fwd, s_bwd;
-    int dbg;              // tuning only (AETH_FIR_DBG): 4 = gather the twiddles instead of the per-lane table
     // chirp-z (Bluestein) mode: a block is one frame of frame_n < N samples, multiplied by chirp[e] on the way in
     // and on the way out, zero beyond frame_n; conj = transform with the other exponent sign
     const cf *chirp = nullptr;
@@ -37,8 +36,7 @@ struct FmiArgs {
     unsigned char *bits = nullptr;    // n * bps bytes, one per bit
     cf tab[4] = {};                   // BPSK / QPSK symbol table
     int bps = 0, demod_compat = 0;
-    int demod_sep = 0;                // QPSK table of the form {(a,c), (b,c), (a,d), (b,d)} (the generic one is): the four
-                                      // distances share their squared terms -- same rounded values, half the arithmetic
+    int demod_sep = 0;                // host side only: picks the kernel build (DM_QSEP / DM_QGEN, see demod_block)
 };
 
 // Kernel variants (template parameter VAR, a bit set).  0 is the round-1 kernel.
@@ -59,6 +57,7 @@ enum : int {
     V_SPREAD = 16384, // the next window's 16 loads issued in four groups between the passes of this block's forward
                     // transform instead of one burst in front of it (the TA command FIFO is full 40 % of the time)
     V_DEMOD = 1024, // product variant: hard demodulation instead of the sample store (aeth_fft_mul_ifft_demod)
+    V_DM_BPSK = 1 << 16, V_DM_QGEN = 1 << 17,   // with V_DEMOD: the decision's mode (neither: QPSK, separable table)
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
     V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
     V_CENSUS = 256, // diagnosis only: every wave records HW_ID / XCC_ID in the buffer passed as `chirp`
@@ -68,7 +67,7 @@ enum : int {
 
 // What libaether_hip.so may instantiate; everything else is measurement / diagnosis and builds only where
 // AETH_FIR_LAB is defined non-zero before this header is included (tools/fir_lab.hip)
-constexpr int V_PRODUCT_MASK = V_PRIO | V_XOR | V_SPREAD | V_DECIM | V_DEMOD;
+constexpr int V_PRODUCT_MASK = V_PRIO | V_XOR | V_SPREAD | V_DECIM | V_DEMOD | V_DM_BPSK | V_DM_QGEN;
 #ifndef AETH_FIR_LAB
 #define AETH_FIR_LAB 0
 #endif
@@ -200,58 +199,97 @@ __device__ __forceinline__ unsigned touch_window(const FmiArgs &a, long long blk
     return acc;
 }
 
-// CHECK = false: the caller knows that the block exists (no branch around the stores, so that hipcc keeps
-// counting the memory operations in flight across them)
 // Modulation::demod_naive on the block's output samples (modulation.rs:33-56 for [cf32; 4], :133-144 for [cf32; 2]):
-// nearest table symbol by squared distance, first minimum wins; bit bytes to a.bits.  The products are rounded
-// before the sum (opaque asm: this file is built with -ffp-contract=fast, the stand-alone demod kernel without),
-// so the decisions are those of aeth_demod_naive on the stored samples.
-template <class C, bool SCALED>
-__device__ __forceinline__ void demod_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
+// nearest table symbol by squared distance, d = rn(rn(dr*dr) + rn(di*di)) -- the products are rounded before the sum
+// (packed multiplies and adds as asm statements: nothing for -ffp-contract=fast to fuse), so the decisions are those
+// of aeth_demod_naive on the stored samples -- folded as the reference's min_by does: the running minimum is replaced
+// by a strictly smaller distance and by an unordered pair (`v_cmp_nle`: !(best <= d)), equal distances keep the first.
+//
+// Same skeleton as store_block<CHECK = false>: no branch anywhere.  The mode (DM) is a template parameter, the bit
+// bytes leave through a per-block buffer descriptor whose range check drops what must not be written (a block past
+// the end: zero-length descriptor; samples in front of the valid part: offset out of range), so hipcc can count the
+// memory operations in flight and the loop's only wait stays `vmcnt(16)`.
+//   DM_BPSK  two candidates, one byte per sample
+//   DM_QSEP  QPSK table of the form {(a,c), (b,c), (a,d), (b,d)} (the generic one is): the four distances are built
+//            from four squares instead of eight -- six packed instructions per sample, bit for bit the values of DM_QGEN
+//   DM_QGEN  any other four-entry table
+enum : int { DM_BPSK = 1, DM_QSEP = 2, DM_QGEN = 3 };
+
+// (a.x - t.x, a.x - t.y) / (a.y - t.x, a.y - t.y): one sample component against two table components (t wave-uniform)
+__device__ __forceinline__ cf diff_re(cf a, cf t) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "s"(t)); return d; }
+__device__ __forceinline__ cf diff_im(cf a, cf t) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "s"(t)); return d; }
+__device__ __forceinline__ cf pk_sq(cf a) { cf d; asm("v_pk_mul_f32 %0, %1, %1" : "=v"(d) : "v"(a)); return d; }
+__device__ __forceinline__ cf pk_sum(cf a, cf b) { cf d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// (a.x + b.x, a.y + b.x) and (a.x + b.y, a.y + b.y)
+__device__ __forceinline__ cf pk_sum_lo(cf a, cf b) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ cf pk_sum_hi(cf a, cf b) { cf d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
+// wave-uniform operands of the decision, built once per launch from the table in the kernel arguments
+struct DemodK {
+    cf x01, y01, x23, y23;      // (t0.x, t1.x), (t0.y, t1.y), (t2.x, t3.x), (t2.y, t3.y); DM_QSEP uses x01 and (t0.y, t2.y) in y01
+    unsigned hi;                // what bit 1 of the index contributes to the stored pair of bytes: 0x100, or 0x200 for `idx & 2` (modulation.rs:54)
+};
+
+template <int DM>
+__device__ __forceinline__ DemodK demod_consts(const FmiArgs &a)
 {
-    const long long base = blk * a.hop - a.ov;
-    const cf ss = mk(a.s_bwd, a.s_bwd);
-    const int ncand = a.bps * 2;                             // the trait default scans BITS_PER_SYMBOL*2 (:135); QPSK: all four
-#pragma unroll
-    for (int m = 0; m < C::P; m++) {
-        const int e = tid + m * C::T;
-        const long long o = base + e;
-        const cf v = SCALED ? cscale_k(w[m], ss) : w[m];
-        unsigned best = 0;
-        float bd = 0.f;
-        if (a.demod_sep) {
-            // d_c = rn(rn((x - t_c.x)^2) + rn((y - t_c.y)^2)) with t_0.x == t_2.x, t_1.x == t_3.x, t_0.y == t_1.y, t_2.y == t_3.y:
-            // the four sums are built from four squares instead of eight -- bit for bit the values of the loop below
-            const float dx0 = v.x - a.tab[0].x, dx1 = v.x - a.tab[1].x, dy0 = v.y - a.tab[0].y, dy1 = v.y - a.tab[2].y;
-            float px0 = dx0 * dx0, px1 = dx1 * dx1, py0 = dy0 * dy0, py1 = dy1 * dy1;
-            asm volatile("" : "+v"(px0), "+v"(px1), "+v"(py0), "+v"(py1));
-            const float d0 = px0 + py0, d1 = px1 + py0, d2 = px0 + py1, d3 = px1 + py1;
-            bd = d0;
-            if (!(bd <= d1)) { best = 1u; bd = d1; }                         // min_by: aeth_modulation.hip, nearest()
-            if (!(bd <= d2)) { best = 2u; bd = d2; }
-            if (!(bd <= d3)) { best = 3u; bd = d3; }
+    DemodK k;
+    k.x01 = mk(a.tab[0].x, a.tab[1].x); k.y01 = mk(a.tab[0].y, DM == DM_QSEP ? a.tab[2].y : a.tab[1].y);
+    k.x23 = mk(a.tab[2].x, a.tab[3].x); k.y23 = mk(a.tab[2].y, a.tab[3].y);
+    k.hi = a.demod_compat ? 0x200u : 0x100u;
+    return k;
+}
+
+// the bytes demod_naive emits for one sample: bit 0 of the index in byte 0, bit 1 (or idx & 2) in byte 1
+template <int DM>
+__device__ __forceinline__ unsigned demod_decide(cf v, const DemodK &k)
+{
+    if constexpr (DM == DM_BPSK) {
+        const cf d = pk_sum(pk_sq(diff_re(v, k.x01)), pk_sq(diff_im(v, k.y01)));     // (d0, d1)
+        return !(d.x <= d.y) ? 1u : 0u;
+    } else {
+        cf d01, d23;
+        if constexpr (DM == DM_QSEP) {
+            const cf px = pk_sq(diff_re(v, k.x01)), py = pk_sq(diff_im(v, k.y01));   // (px0, px1), (py0, py1)
+            d01 = pk_sum_lo(px, py); d23 = pk_sum_hi(px, py);
         } else {
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (c < ncand) {
-                    const float dr = v.x - a.tab[c].x, di = v.y - a.tab[c].y;
-                    float p0 = dr * dr, p1 = di * di;
-                    asm volatile("" : "+v"(p0), "+v"(p1));
-                    const float d = p0 + p1;
-                    if (c == 0 || !(bd <= d)) { best = (unsigned)c; bd = d; }     // min_by: aeth_modulation.hip, nearest()
-                }
-            }
+            d01 = pk_sum(pk_sq(diff_re(v, k.x01)), pk_sq(diff_im(v, k.y01)));
+            d23 = pk_sum(pk_sq(diff_re(v, k.x23)), pk_sq(diff_im(v, k.y23)));
         }
-        if (e >= a.ov && o < a.n && e < a.frame_n) {
-            if (a.bps == 1) a.bits[o] = (unsigned char)(best & 1u);
-            else {
-                const unsigned hi = a.demod_compat ? (best & 2u) : ((best >> 1) & 1u);          // modulation.rs:54
-                *reinterpret_cast<unsigned short *>(a.bits + 2 * o) = (unsigned short)((best & 1u) | (hi << 8));
-            }
-        }
+        const bool c1 = !(d01.x <= d01.y);
+        const float b1 = c1 ? d01.y : d01.x;
+        const bool c2 = !(b1 <= d23.x);
+        const float b2 = c2 ? d23.x : b1;
+        const bool c3 = !(b2 <= d23.y);
+        const bool bit0 = c3 | (c1 & !c2), bit1 = c3 | c2;                           // index = c3 ? 3 : c2 ? 2 : c1 ? 1 : 0
+        return (bit0 ? 1u : 0u) | (bit1 ? k.hi : 0u);
     }
 }
 
+template <class C, bool SCALED, bool NT, int DM>
+__device__ __forceinline__ void demod_block(const cf (&w)[C::P], const FmiArgs &a, const DemodK &k, long long blk, int tid)
+{
+    static_assert(C::F == 1, "demodulating store: one block per workgroup");
+    constexpr int B = DM == DM_BPSK ? 1 : 2;                        // bytes per sample
+    const long long base = blk * a.hop - a.ov;
+    long long left = a.n - base;
+    int bytes = (int)(left < a.frame_n ? left : a.frame_n) * B;
+    if (blk >= a.nblocks) bytes = 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(a.bits + base * B, 0, bytes, 0x00020000);
+    const cf ss = mk(a.s_bwd, a.s_bwd);
+#pragma unroll
+    for (int m = 0; m < C::P; m++) {
+        const int e = tid + m * C::T;
+        const int off = (e >= a.ov) ? e * B : 0x7ffffff0;
+        const cf v = SCALED ? cscale_k(w[m], ss) : w[m];
+        const unsigned o = demod_decide<DM>(v, k);
+        if constexpr (B == 1) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)o, rs, off, 0, NT ? AETH_FIR_STORE_AUX : 0);
+        else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)o, rs, off, 0, NT ? AETH_FIR_STORE_AUX : 0);
+    }
+}
+
+// CHECK = false: the caller knows that the block exists (no branch around the stores, so that hipcc keeps
+// counting the memory operations in flight across them)
 template <class C, bool SCALED, bool NT, bool CHECK = true, bool DECIM = false>
 __device__ __forceinline__ void store_block(const cf (&w)[C::P], const FmiArgs &a, long long blk, int tid)
 {
@@ -385,6 +423,10 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
     constexpr bool TOUCH = (VAR & V_TOUCH) && C::F == 1 && !BLU;
     constexpr int TOUCH_AHEAD = (VAR & V_TOUCH3) ? 3 : 2;
     cf nx[C::P], tw[C::TW], H[C::P];
+    constexpr int DM = (VAR & V_DM_BPSK) ? DM_BPSK : (VAR & V_DM_QGEN) ? DM_QGEN : DM_QSEP;
+    static_assert(!(VAR & (V_DM_BPSK | V_DM_QGEN)) || (VAR & V_DEMOD), "decision mode without V_DEMOD");
+    [[maybe_unused]] DemodK dk;
+    if constexpr (VAR & V_DEMOD) dk = demod_consts<DM>(a);
     unsigned bid = blockIdx.x;
     if constexpr ((VAR & V_XCD) != 0) {
         if ((gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -410,7 +452,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         }
         if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f);
         transform_block<C, SCALED, BLU, VAR>(w, tw, H, lds, a, tid);
-        if constexpr (VAR & V_DEMOD) demod_block<C, SCALED>(w, a, g0, tid);
+        if constexpr (VAR & V_DEMOD) demod_block<C, SCALED, NT, DM>(w, a, dk, g0, tid);
         else store_block<C, SCALED, NT, false, (VAR & V_DECIM) != 0>(w, a, g0, tid);     // grid <= ngroups: the block exists
         g0 += gridDim.x;
     } else {
@@ -475,7 +517,7 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         if constexpr (VAR & V_NOSTORE) {
 #pragma unroll
             for (int m = 0; m < C::P; m++) asm volatile("" ::"v"(w[m]));
-        } else if constexpr (VAR & V_DEMOD) { if (blk < a.nblocks) demod_block<C, SCALED>(w, a, blk, tid); }
+        } else if constexpr (VAR & V_DEMOD) demod_block<C, SCALED, NT, DM>(w, a, dk, blk, tid);
         else store_block<C, SCALED, NT, true, (VAR & V_DECIM) != 0>(w, a, blk, tid);
     }
     if constexpr (TOUCH) asm volatile("" ::"v"(tprev));

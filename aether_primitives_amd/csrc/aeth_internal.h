@@ -56,9 +56,19 @@ hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintpt
 // ensure staging slot `i` holds >= bytes of device memory
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes);
 
-// Tuning knobs (tools/tune_*.py): environment integers that are consulted ONLY when the
-// process was started with AETH_TUNING=1; a normal run never reads them.
+// Tuning knobs: environment integers that are consulted ONLY when the process was started with AETH_TUNING=1; a
+// normal run never reads them.  libaether_hip.so carries the seven that choose between SHIPPED behaviours, all
+// documented in include/aether_hip.h ("Tuning knobs"): AETH_FIR_GRID_FIRST, AETH_FIR_GRID_CHAINED, AETH_FIR_SPREAD,
+// AETH_NT, AETH_PIPE_THREADS, AETH_PIPE_MIXED, AETH_SYNC_SPIN_US.
 int tuning_int(const char *name, int dflt);
+// Lab knobs (tools/tune_*.py, prime_route.py, vs_rocfft.py sweeps): routes and shapes that were measured and not
+// kept.  They exist only in the lab build (`make LAB=1` -> lib/libaether_hip_lab.so, -DAETH_LAB=1); in the product
+// every lab_int() is its default at compile time, so the paths behind the other values are not in the library.
+#if defined(AETH_LAB) && AETH_LAB
+inline int lab_int(const char *name, int dflt) { return tuning_int(name, dflt); }
+#else
+constexpr int lab_int(const char *, int dflt) { return dflt; }
+#endif
 
 inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -130,6 +130,8 @@ int main(int argc, char **argv)
         {"xor+prio/g768/2q", 2052, 2, 768}, {"xor+prio/g896/2q", 2052, 2, 896}, {"xor+prio/g768", 2052, 0, 768},
         {"xor+prio/g704/2q", 2052, 2, 704}, {"xor+prio/g736/2q", 2052, 2, 736}, {"xor+prio/g800/2q", 2052, 2, 800},
         {"xor+prio/g832/2q", 2052, 2, 832}, {"xor+prio/g960/2q", 2052, 2, 960},
+        // round 4: 8457 blocks = 11 x 768 + 9 -- grids that divide the stream into whole rounds (769: 11 rounds, 705: 12, 846: 10)
+        {"xor+prio/g769/2q", 2052, 2, 769}, {"xor+prio/g705/2q", 2052, 2, 705}, {"xor+prio/g846/2q", 2052, 2, 846},
         {"nolds/2q", 128, 2, 0}, {"prio/2q", 4, 2, 0}, {"peel/2q", 1, 2, 0},
         {"nomem", 48, 0, 0}, {"nomem/g768", 48, 0, 768}, {"nomem/g512", 48, 0, 512}, {"nomem/g256", 48, 0, 256},
     };
@@ -189,7 +191,6 @@ int main(int argc, char **argv)
     const int cap = prop.multiProcessorCount * 8 / (C2048::WG / 64);
     auto args_for = [&](int b) {
         FmiArgs a;
-        a.dbg = 0;
         a.in = (const cf *)in[b]; a.out = (cf *)out[b]; a.hist = nullptr; a.Hf = (const cf *)fir->Hf;
         a.twN = (const cf *)fir->fft->tw_dev; a.twL = (const cf *)fir->fft->tw_lane_dev;
         a.n = (long long)NS; a.hop = (int)fir->hop; a.ov = (int)(fir->fft_len - fir->hop); a.nhist = (int)(fir->ntaps - 1);
