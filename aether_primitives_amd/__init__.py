@@ -20,6 +20,7 @@ from . import modulation                                  # noqa: E402
 from . import noise                                       # noqa: E402
 from . import file                                        # noqa: E402
 from . import pool                                        # noqa: E402
+from . import pipeline                                    # noqa: E402
 from .evm import assert_evm, evm_db                       # noqa: E402
 
 __all__ = ["AetherError", "LengthMismatch", "Context", "DeviceVec", "HostVec", "Scale", "HipFft",

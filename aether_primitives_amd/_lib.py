@@ -94,6 +94,11 @@ PROTOTYPES = {
     "aeth_host_register": (i32, [vp, vp, sz]),
     "aeth_host_unregister": (i32, [vp, vp]),
     "aeth_host_is_pinned": (i32, [vp, sz]),
+    "aeth_stream_out_count": (sz, [vp, vp, sz]),
+    "aeth_stream_host": (i32, [vp, vp, vp, sz, vp, sz, sz, vp]),
+    "aeth_stream_host_util": (i32, [vp, vp, vp, sz, vp, sz, sz, vp]),
+    "aeth_ctx_trim": (i32, [vp]),
+    "aeth_test_fail_staging_after": (None, [i32]),
     "aeth_fir_stream_host": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_fir_stream_host_util": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_fir_stream_file": (i32, [vp, C.c_char_p, C.c_char_p, sz, vp]),

@@ -46,6 +46,11 @@ class Context:
     def sync(self):
         check(self._lib.aeth_ctx_sync(self.h))
 
+    def trim(self):
+        """Give back what the context retains between calls (host pipeline: stage streams, device slots, pinned staging
+        elements, copy threads; the device scratch of the host-slice flavours)."""
+        check(self._lib.aeth_ctx_trim(self.h))
+
     def set_overlap(self, enable=True):
         """Let consecutive independent `Fir.filter` launches alternate between two HIP queues (the end of one
         launch then runs beside the start of the next); everything else stays ordered as on one stream."""

@@ -132,6 +132,14 @@ int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a, hipStream_t st
 
 bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
 
+// [a, a + na) and [b, b + nb) share a byte?  (elements of 8 bytes)
+bool touch(const aeth_cf32 *a, size_t na, const aeth_cf32 *b, size_t nb)
+{
+    if (!a || !b || !na || !nb) return false;
+    const uintptr_t a0 = (uintptr_t)a, a1 = a0 + na * sizeof(aeth_cf32), b0 = (uintptr_t)b, b1 = b0 + nb * sizeof(aeth_cf32);
+    return a0 < b1 && b0 < a1;
+}
+
 }  // namespace
 
 namespace aeth {
@@ -290,7 +298,10 @@ int aeth_fir_exec(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_
     AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
     if (n == 0) return AETH_OK;
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
-    AETH_REQUIRE(in != out, AETH_E_ARG, "FIR cannot run in place (blocks overlap)");
+    // blocks run concurrently and their windows reach into the neighbours' outputs: ANY overlap of the output range
+    // with the input or the history reads samples that were already overwritten (out = in + 100 as much as out = in)
+    AETH_REQUIRE(!touch(out, n, in, n) && !touch(out, n, hist, f->ntaps - 1), AETH_E_ARG,
+                 "FIR cannot run in place: the output range overlaps the input (or its history)");
     AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out) && aeth::aligned8(hist), AETH_E_ALIGN,
                  "pointer not 8-byte aligned");
     FmiArgs a;
@@ -316,7 +327,8 @@ int aeth_fir_exec_decim(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in,
     const size_t dec = n / n_out;
     if (dec == 1) return aeth_fir_exec(f, hist, in, n, out);
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
-    AETH_REQUIRE(in != out, AETH_E_ARG, "FIR cannot run in place (blocks overlap)");
+    AETH_REQUIRE(!touch(out, n_out, in, n) && !touch(out, n_out, hist, f->ntaps - 1), AETH_E_ARG,
+                 "FIR cannot run in place: the output range overlaps the input (or its history)");
     AETH_REQUIRE(aeth::aligned8(in) && aeth::aligned8(out) && aeth::aligned8(hist), AETH_E_ALIGN,
                  "pointer not 8-byte aligned");
     AETH_REQUIRE(f->fft_len >= 1024 && f->fft_len <= 4096, AETH_E_UNSUPPORTED,

@@ -5,9 +5,14 @@
 //
 //     copy-in        caller slice  -> pinned pool element          host threads (CopyTeam)
 //     upload         pinned        -> device slot                  HIP stream 0 (H2D copy engine)
-//     kernel         fused FFT*H*IFFT on the slot                  HIP stream 1
+//     compute        one of the library's device ops on the slot   HIP stream 1
 //     download       device slot   -> pinned pool element          HIP stream 2 (D2H copy engine)
 //     copy-out       pinned        -> caller slice                 host threads
+//
+// The reference's pipeline takes an arbitrary closure per stage (pipeline.rs:24-41 `add_stage<F: FnMut(O) -> U>`,
+// :123-137 `new`); a closure cannot cross the C ABI, so the compute stage is an op descriptor (aeth_stream_op): the
+// fused FIR, batched FFT frames, the correlator chain, correlate + demod (8 B in, 1-2 B out per sample) or FFT +
+// interpolate (1 sample in, n_between + 1 out) -- input and output chunks differ in element size and count per op.
 //
 // Slots are handed from stage to stage by events (device stages) and completion counters (host stages); the
 // calling thread only enqueues and polls.  A side whose caller memory is ALREADY page-locked -- it lies inside an
@@ -21,57 +26,20 @@
 
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <new>
 
 namespace aeth {
 
-// ---- copy threads ---------------------------------------------------------------------------
-CopyTeam::CopyTeam(int nthreads)
+static std::atomic<int> g_fail_after{0};
+void pipe_fail_arm(int n) { g_fail_after.store(n); }
+// true exactly once: when the armed count reaches zero
+bool pipe_fail_after_take()
 {
-    if (nthreads < 1) nthreads = 1;
-    for (int i = 0; i < nthreads; i++) th_.emplace_back([this] { run(); });
-}
-
-CopyTeam::~CopyTeam()
-{
-    { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto &t : th_) t.join();
-}
-
-void CopyTeam::submit(void *dst, const void *src, size_t bytes, std::atomic<int> *pending)
-{
-    if (bytes == 0) return;
-    // slices of 1-4 MiB: enough of them for every thread, each long enough to amortise the hand-over
-    size_t slice = bytes / (size_t)(2 * th_.size());
-    const size_t lo = (size_t)1 << 20, hi = (size_t)4 << 20;
-    slice = slice < lo ? lo : (slice > hi ? hi : slice);
-    slice = (slice + 4095) & ~(size_t)4095;
-    const int n = (int)((bytes + slice - 1) / slice);
-    pending->fetch_add(n, std::memory_order_relaxed);
-    {
-        std::lock_guard<std::mutex> l(mu_);
-        for (size_t off = 0; off < bytes; off += slice)
-            q_.push_back(Job{(char *)dst + off, (const char *)src + off, bytes - off < slice ? bytes - off : slice, pending});
-    }
-    if (n > 1) cv_.notify_all(); else cv_.notify_one();
-}
-
-void CopyTeam::run()
-{
-    for (;;) {
-        Job j;
-        {
-            std::unique_lock<std::mutex> l(mu_);
-            cv_.wait(l, [this] { return stop_ || !q_.empty(); });
-            if (q_.empty()) return;             // stop_ and nothing left
-            j = q_.front();
-            q_.pop_front();
-        }
-        memcpy(j.dst, j.src, j.bytes);
-        j.pending->fetch_sub(1, std::memory_order_release);
-    }
+    int v = g_fail_after.load();
+    while (v > 0) { if (g_fail_after.compare_exchange_weak(v, v - 1)) return v == 1; }
+    return false;
 }
 
 void pipe_release(aeth_ctx *ctx)
@@ -88,7 +56,8 @@ void pipe_release(aeth_ctx *ctx)
         if (p->ran[s]) (void)hipEventDestroy(p->ran[s]);
         if (p->down[s]) (void)hipEventDestroy(p->down[s]);
     }
-    (void)pool_destroy_forced(p->pool);
+    (void)pool_destroy_forced(p->pool[0]);
+    (void)pool_destroy_forced(p->pool[1]);
     delete p;
     ctx->pipe = nullptr;
 }
@@ -105,7 +74,30 @@ double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// streams, events, device slots of `din_bytes` / `dout_bytes`, grown (never shrunk) between calls
+// What the compute stage does with one chunk.  Elements are the op's own (cf32 samples in; samples or bit bytes out).
+struct StageOp {
+    aeth_ctx *ctx = nullptr;
+    size_t in_unit = 8, out_unit = 8;      // bytes per input / output element
+    size_t hist = 0;                       // input elements of left context in front of every chunk (FIR: ntaps - 1)
+    size_t align = 1;                      // chunk granularity in input elements (FIR: hop; frame ops: the frame length)
+    size_t out_per_align = 1;              // output elements per `align` input elements (out_count is linear in the input)
+    bool inplace = false;                  // the op leaves its result in the input slot (aeth_fft_mul_ifft)
+    // din_chunk: first input element of the chunk in the device slot (hist elements of context in front of it when
+    // have_hist); runs on `s` and must not wait for the host
+    std::function<int(hipStream_t s, const void *din_hist, void *din_chunk, bool have_hist, size_t cnt, void *dout, size_t cnt_out)> run;
+    size_t out_count(size_t cnt) const { return cnt / align * out_per_align + (cnt % align) * out_per_align / align; }
+};
+
+// While an op of the public API runs for the pipeline, the context's stream IS the compute stage's stream: every
+// entry point launches on aeth::ctx_stream(ctx).  A context is used by one thread at a time (aether_hip.h), and the
+// pipeline has drained the context's own stream before its first chunk, so nothing else can be enqueued meanwhile.
+struct StreamSwap {
+    aeth_ctx *c; hipStream_t saved; bool overlap;
+    StreamSwap(aeth_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream_main), overlap(ctx->overlap) { c->stream_main = s; c->overlap = false; c->chain_last = -1; }
+    ~StreamSwap() { c->stream_main = saved; c->overlap = overlap; c->chain_last = -1; }
+};
+
+// streams, events, device slots of `din_bytes` / `dout_bytes`, grown (never shrunk; aeth_ctx_trim releases) between calls
 int pipe_prepare(aeth_ctx *ctx, size_t din_bytes, size_t dout_bytes, int nslots)
 {
     if (!ctx->pipe) {
@@ -136,28 +128,9 @@ int pipe_prepare(aeth_ctx *ctx, size_t din_bytes, size_t dout_bytes, int nslots)
         if (!p->din[s]) AETH_HIP(hipMalloc((void **)&p->din[s], p->din_bytes));
         if (!p->dout[s]) AETH_HIP(hipMalloc((void **)&p->dout[s], p->dout_bytes));
     }
-    return AETH_OK;
-}
-
-// `count` pinned staging elements of at least `bytes` each from the context's pool (rebuilt when a run needs larger ones)
-int pipe_take_staging(aeth_ctx *ctx, size_t bytes, int count, void **out)
-{
-    PipeState *p = ctx->pipe;
-    if (p->pool && aeth_pool_elem_bytes(p->pool) < bytes) {
-        int rc = aeth_pool_destroy(p->pool);        // every element is back between runs
-        p->pool = nullptr;
-        if (rc) return rc;
-    }
-    if (!p->pool) {
-        int rc = aeth_pool_create(ctx, bytes, 0, 0, &p->pool);
-        if (rc) return rc;
-    }
-    for (int i = 0; i < count; i++) {
-        int rc = aeth_pool_take_or_make(p->pool, &out[i]);
-        if (rc) { for (int j = 0; j < i; j++) (void)aeth_pool_give_back(p->pool, out[j]); return rc; }
-    }
     if (!p->team) {
-        // half of the cores this process may run on, 2 .. 12 (tuning: AETH_PIPE_THREADS)
+        // half of the cores this process may run on, 2 .. 12 (tuning: AETH_PIPE_THREADS).  Created BEFORE any staging
+        // element is taken, so that no error path between the two leaves elements checked out.
         int hw = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) hw = c; }
@@ -169,52 +142,98 @@ int pipe_take_staging(aeth_ctx *ctx, size_t bytes, int count, void **out)
     return AETH_OK;
 }
 
-// hist: ntaps-1 host samples in front of `in` (null: zeros), as in aeth_fir_exec_host
+// `count` pinned staging elements of at least `bytes` each from the context's pool for side `side` (0 in, 1 out; the
+// pool is rebuilt when a run needs larger elements).  On ANY failure nothing stays checked out and the pool a refused
+// aeth_pool_destroy leaves behind stays where it is (still owned, still usable for smaller runs).
+int pipe_take_staging(aeth_ctx *ctx, int side, size_t bytes, int count, void **out)
+{
+    PipeState *p = ctx->pipe;
+    if (p->pool[side] && aeth_pool_elem_bytes(p->pool[side]) < bytes) {
+        int rc = aeth_pool_destroy(p->pool[side]);  // every element is back between runs
+        if (rc) return rc;                          // refused: the pool stays
+        p->pool[side] = nullptr;
+    }
+    if (!p->pool[side]) {
+        int rc = aeth_pool_create(ctx, bytes, 0, 0, &p->pool[side]);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < count; i++) {
+        int rc = aeth_pool_take_or_make(p->pool[side], &out[i]);
+        if (rc == AETH_OK && aeth::pipe_fail_after_take() ) rc = aeth::set_error(AETH_E_NOMEM, "staging: forced failure (test hook)");
+        if (rc) {
+            for (int j = 0; j <= i; j++) if (out[j]) { (void)aeth_pool_give_back(p->pool[side], out[j]); out[j] = nullptr; }
+            return rc;
+        }
+    }
+    return AETH_OK;
+}
+
+// The largest slot (one side of one chunk) the pipeline sizes by itself or accepts from the caller: a larger
+// chunk_samples is split internally.  Keeps what a context retains between runs bounded: 3 device slots per side and,
+// for pageable caller memory, 3 pinned elements per side -- at most 6 x 64 MiB each of device and of pinned memory.
+constexpr size_t kMaxSlotBytes = (size_t)64 << 20;
+
+// hist: op.hist host elements in front of `in` (null: zeros), as in aeth_fir_exec_host
 // util: per-stage active time as well (the device-side counterpart of the reference's per-stage utilisation
 // report, src/pipeline.rs:89-114): timed events around every device stage operation, wall clock around the host ones
-int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk,
-                    aeth_pipe_stats *stats, aeth_pipe_util *util = nullptr)
+int stream_host(const StageOp &op, const void *hist, const void *in_, size_t n, void *out_, size_t n_out, size_t chunk,
+                aeth_pipe_stats *stats, aeth_pipe_util *util = nullptr)
 {
-    AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
     if (util) *util = aeth_pipe_util{0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0};
+    AETH_REQUIRE(n_out == op.out_count(n), AETH_E_LEN, "output holds %zu elements, the op produces %zu from %zu", n_out, op.out_count(n), n);
     if (n == 0) return AETH_OK;
-    AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
-    AETH_REQUIRE(in != out, AETH_E_ARG, "FIR cannot run in place (blocks overlap)");
-    aeth_ctx *ctx = f->ctx;
-    aeth::DeviceGuard g(ctx->device);
-    const size_t nh = f->ntaps - 1;
-    // chunk: 32 MiB of samples per transfer for long streams, an eighth of a short one (so that its copies still
-    // overlap), never under 1 MiB; hop-aligned, so the blocks are those of the one-shot run
-    if (chunk == 0) {
-        chunk = (size_t)4 << 20;
-        if (n / 8 < chunk) chunk = n / 8;
-        if (chunk < ((size_t)128 << 10)) chunk = (size_t)128 << 10;
+    AETH_REQUIRE(in_ && out_, AETH_E_ARG, "null pointer");
+    const char *in = (const char *)in_;
+    char *out = (char *)out_;
+    const size_t IU = op.in_unit, OU = op.out_unit, nh = op.hist;
+    {   // the stream is read while its head is already being written: the two host ranges must not touch
+        const uintptr_t a0 = (uintptr_t)in, a1 = a0 + n * IU, b0 = (uintptr_t)out, b1 = b0 + n_out * OU;
+        AETH_REQUIRE(a1 <= b0 || b1 <= a0, AETH_E_ARG, "input and output ranges overlap");
     }
-    if (chunk > n) chunk = n;
-    chunk = ((chunk + f->hop - 1) / f->hop) * f->hop;
+    aeth_ctx *ctx = op.ctx;
+    aeth::DeviceGuard g(ctx->device);
+    // chunk: 32 MiB on the larger side per transfer for long streams, an eighth of a short one (so that its copies
+    // still overlap), never under 1 MiB; a whole number of `align` units, so every chunk runs the blocks / frames the
+    // one-shot call would
+    const size_t per_in = IU * op.align, per_out = OU * op.out_per_align;             // bytes per align unit
+    const size_t per_max = per_in > per_out ? per_in : per_out;
+    auto units_for = [&](size_t bytes) { size_t u = bytes / per_max; return u < 1 ? (size_t)1 : u; };
+    const size_t n_units = (n + op.align - 1) / op.align;
+    size_t cu;                                                                        // chunk in align units
+    if (chunk == 0) {
+        cu = units_for((size_t)32 << 20);
+        if (n_units / 8 < cu) cu = n_units / 8;
+        const size_t lo = units_for((size_t)1 << 20);
+        if (cu < lo) cu = lo;
+    } else cu = (chunk + op.align - 1) / op.align;
+    if (cu > units_for(kMaxSlotBytes)) cu = units_for(kMaxSlotBytes);
+    if (cu > n_units) cu = n_units;
+    chunk = cu * op.align;
+    const size_t chunk_out = op.out_count(chunk);
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int nslots = (int)(nchunks < (size_t)kPipeSlots ? nchunks : (size_t)kPipeSlots);
-    const size_t in_slot_bytes = (chunk + nh) * sizeof(float2), out_slot_bytes = chunk * sizeof(float2);
+    const size_t in_slot_bytes = (chunk + nh) * IU, out_slot_bytes = chunk_out * OU;
 
     // a side that is already page-locked is copied from / to directly; anything else goes through pinned staging
-    const bool stage_in = !aeth::host_range_pinned(in, n * sizeof(float2));
-    bool stage_out = !aeth::host_range_pinned(out, n * sizeof(float2));
+    const bool stage_in = !aeth::host_range_pinned(in, n * IU);
+    bool stage_out = !aeth::host_range_pinned(out, n_out * OU);
     // A staged input next to a directly written output is the one combination that measured badly: with 256 Mi
     // samples the downloads into the caller's (pinned) 2 GiB slice took 2.4 x as long while the copy threads fed the
-    // uploads (2.3-2.9 GS/s, profiles/r03_stream_host.txt; cause not found), where staging BOTH sides runs at the
-    // rate of the all-pinned case (5.6 GS/s) -- so an input that needs the host stage takes the output through it too.
+    // uploads (2.3-2.9 GS/s, profiles/r03_stream_host.txt), where staging BOTH sides runs at the rate of the
+    // all-pinned case (5.6 GS/s) -- so an input that needs the host stage takes the output through it too
+    // (AETH_PIPE_MIXED=1 under AETH_TUNING=1 keeps the direct download; include/aether_hip.h, "Tuning knobs").
     if (stage_in && !stage_out && aeth::tuning_int("AETH_PIPE_MIXED", 0) == 0) stage_out = true;
 
-    int rc = pipe_prepare(ctx, in_slot_bytes, out_slot_bytes, nslots);
+    int rc = pipe_prepare(ctx, in_slot_bytes, op.inplace ? 16 : out_slot_bytes, nslots);
     if (rc) return rc;
     PipeState *ps = ctx->pipe;
-    void *pin[2 * kPipeSlots] = {};
-    const int npin = (stage_in ? nslots : 0) + (stage_out ? nslots : 0);
-    if (npin) { rc = pipe_take_staging(ctx, in_slot_bytes, npin, pin); if (rc) return rc; }
-    float2 *pin_in[kPipeSlots] = {}, *pin_out[kPipeSlots] = {};
-    { int k = 0; if (stage_in) for (int s = 0; s < nslots; s++) pin_in[s] = (float2 *)pin[k++];
-                 if (stage_out) for (int s = 0; s < nslots; s++) pin_out[s] = (float2 *)pin[k++]; }
+    void *pin_in[kPipeSlots] = {}, *pin_out[kPipeSlots] = {};
+    if (stage_in) { rc = pipe_take_staging(ctx, 0, in_slot_bytes, nslots, pin_in); if (rc) return rc; }
+    if (stage_out) {
+        rc = pipe_take_staging(ctx, 1, out_slot_bytes, nslots, pin_out);
+        if (rc) { if (stage_in) for (int s = 0; s < nslots; s++) (void)aeth_pool_give_back(ps->pool[0], pin_in[s]); return rc; }
+    }
 
     hipStream_t s_up = ps->stream[0], s_run = ps->stream[1], s_down = ps->stream[2];
     auto fail = [&](hipError_t e, const char *what) { rc = aeth::hip_fail(e, what); };
@@ -238,10 +257,12 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
     double act_in = 0, act_out = 0, last_in = 0, last_out = 0;
     size_t next_in = 0, next_sub = 0, next_out = 0, fin_in = 0, fin_out = 0;
     auto geom = [&](size_t k, size_t &o0, size_t &cnt, size_t &h) {
-        o0 = k * chunk; cnt = (n - o0 < chunk) ? n - o0 : chunk; h = (o0 >= nh) ? nh : o0;     // h: history samples the source holds
+        o0 = k * chunk; cnt = (n - o0 < chunk) ? n - o0 : chunk; h = (o0 >= nh) ? nh : o0;     // h: history elements the source holds
     };
 
     int idle = 0;
+    {
+    StreamSwap swap(ctx, s_run);
     while (rc == AETH_OK && (next_sub < nchunks || (stage_out && fin_out < nchunks))) {
         bool progress = false;
         // ---- copy-in: chunk k into its slot's pinned element once the upload of chunk k - 3 has left it
@@ -254,9 +275,10 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
             }
             if (free_) {
                 size_t o0, cnt, h; geom(k, o0, cnt, h);
-                if (k == 0 && hist && nh) memcpy(pin_in[s], hist, nh * sizeof(float2));
+                char *pe = (char *)pin_in[s];
+                if (k == 0 && hist && nh) memcpy(pe, hist, nh * IU);
                 t_in[k] = now_s();
-                ps->team->submit(pin_in[s] + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), &in_pending[k]);
+                ps->team->submit(pe + (nh - h) * IU, in + (o0 - h) * IU, (h + cnt) * IU, &in_pending[k]);
                 next_in++; progress = true;
             }
         }
@@ -273,38 +295,40 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
             const bool out_free = !stage_out || k < (size_t)kPipeSlots || fin_out + kPipeSlots > k;
             if (in_ready && out_free) {
                 size_t o0, cnt, h; geom(k, o0, cnt, h);
+                const size_t cnt_out = op.out_count(cnt), oo0 = op.out_count(o0);
                 const bool used = k >= (size_t)kPipeSlots;
-                float2 *din = ps->din[s], *dout = ps->dout[s];
-                // H2D: the slot's input buffer is free once the kernel of chunk k - 3 has run
-                if (used && !ok(hipStreamWaitEvent(s_up, ps->ran[s], 0), "hipStreamWaitEvent")) break;
+                char *din = (char *)ps->din[s], *dout = (char *)ps->dout[s];
+                // H2D: the slot's input buffer is free once the op of chunk k - 3 has run (an in-place op: once its
+                // result has been downloaded)
+                if (used && !ok(hipStreamWaitEvent(s_up, op.inplace ? ps->down[s] : ps->ran[s], 0), "hipStreamWaitEvent")) break;
                 mark(k, 0, 0, s_up);
                 // [zeros | history | chunk] -> device
                 const bool have_hist0 = k == 0 && hist && nh;
                 if (stage_in) {
                     // the pinned element mirrors the slot: history (copied in by the host stage) in front of the chunk
                     const size_t skip = have_hist0 ? 0 : nh - h;
-                    if (skip && !ok(hipMemsetAsync(din, 0, skip * sizeof(float2), s_up), "hipMemsetAsync")) break;
-                    if (!ok(hipMemcpyAsync(din + skip, pin_in[s] + skip, (nh - skip + cnt) * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
+                    if (skip && !ok(hipMemsetAsync(din, 0, skip * IU, s_up), "hipMemsetAsync")) break;
+                    if (!ok(hipMemcpyAsync(din + skip * IU, (char *)pin_in[s] + skip * IU, (nh - skip + cnt) * IU, hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
                 } else {
-                    if (have_hist0) { if (!ok(hipMemcpyAsync(din, hist, nh * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break; }
-                    else if (h < nh && !ok(hipMemsetAsync(din, 0, (nh - h) * sizeof(float2), s_up), "hipMemsetAsync")) break;
-                    if (!ok(hipMemcpyAsync(din + (nh - h), in + (o0 - h), (h + cnt) * sizeof(float2), hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
+                    if (have_hist0) { if (!ok(hipMemcpyAsync(din, hist, nh * IU, hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break; }
+                    else if (h < nh && !ok(hipMemsetAsync(din, 0, (nh - h) * IU, s_up), "hipMemsetAsync")) break;
+                    if (!ok(hipMemcpyAsync(din + (nh - h) * IU, in + (o0 - h) * IU, (h + cnt) * IU, hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
                 }
                 mark(k, 0, 1, s_up);
                 if (!ok(hipEventRecord(ps->up[s], s_up), "hipEventRecord")) break;
-                // kernel: needs the chunk up and the slot's output buffer drained by the D2H of chunk k - 3
+                // compute: needs the chunk up and the slot's output buffer drained by the D2H of chunk k - 3
                 if (!ok(hipStreamWaitEvent(s_run, ps->up[s], 0), "hipStreamWaitEvent")) break;
                 if (used && !ok(hipStreamWaitEvent(s_run, ps->down[s], 0), "hipStreamWaitEvent")) break;
                 mark(k, 1, 0, s_run);
-                rc = aeth::fir_exec_on(f, s_run, (o0 || hist) ? (const aeth_cf32 *)din : nullptr, (const aeth_cf32 *)(din + nh), cnt, (aeth_cf32 *)dout);
+                rc = op.run(s_run, din, din + nh * IU, (o0 || hist) && nh, cnt, dout, cnt_out);
                 if (rc) break;
                 mark(k, 1, 1, s_run);
                 if (!ok(hipEventRecord(ps->ran[s], s_run), "hipEventRecord")) break;
                 // D2H
                 if (!ok(hipStreamWaitEvent(s_down, ps->ran[s], 0), "hipStreamWaitEvent")) break;
                 mark(k, 2, 0, s_down);
-                float2 *dst = stage_out ? pin_out[s] : (float2 *)out + o0;
-                if (!ok(hipMemcpyAsync(dst, dout, cnt * sizeof(float2), hipMemcpyDeviceToHost, s_down), "hipMemcpyAsync D2H")) break;
+                char *dst = stage_out ? (char *)pin_out[s] : out + oo0 * OU;
+                if (!ok(hipMemcpyAsync(dst, op.inplace ? din + nh * IU : dout, cnt_out * OU, hipMemcpyDeviceToHost, s_down), "hipMemcpyAsync D2H")) break;
                 mark(k, 2, 1, s_down);
                 if (!ok(hipEventRecord(ps->down[s], s_down), "hipEventRecord")) break;
                 next_sub++; progress = true;
@@ -317,7 +341,7 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
             if (q == hipSuccess) {
                 size_t o0, cnt, h; geom(k, o0, cnt, h);
                 t_out[k] = now_s();
-                ps->team->submit(out + o0, pin_out[s], cnt * sizeof(float2), &out_pending[k]);
+                ps->team->submit(out + op.out_count(o0) * OU, pin_out[s], op.out_count(cnt) * OU, &out_pending[k]);
                 next_out++; progress = true;
             } else if (q != hipErrorNotReady) { fail(q, "hipEventQuery"); break; }
         }
@@ -331,6 +355,7 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
         if (progress) idle = 0;
         else if (++idle < 32) std::this_thread::yield();
         else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
     }
     (void)hipGetLastError();                                       // hipErrorNotReady from the queries is not an error
     // drain: the device stages, then whatever the copy threads still hold (also on the error path: they write
@@ -361,26 +386,137 @@ int fir_stream_host(aeth_fir *f, const aeth_cf32 *hist, const aeth_cf32 *in, siz
         }
     }
     for (auto m : marks) if (m) (void)hipEventDestroy(m);
-    for (int i = 0; i < npin; i++) {
-        const int r = aeth_pool_give_back(ps->pool, pin[i]);
-        if (r && rc == AETH_OK) rc = r;
+    for (int s = 0; s < nslots; s++) {
+        if (pin_in[s]) { const int r = aeth_pool_give_back(ps->pool[0], pin_in[s]); if (r && rc == AETH_OK) rc = r; }
+        if (pin_out[s]) { const int r = aeth_pool_give_back(ps->pool[1], pin_out[s]); if (r && rc == AETH_OK) rc = r; }
     }
     return rc;
+}
+
+// ---- the ops -------------------------------------------------------------------------------------------------
+int op_fir(aeth_fir *f, StageOp &op)
+{
+    AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
+    op.ctx = f->ctx; op.hist = f->ntaps - 1; op.align = f->hop; op.out_per_align = f->hop;
+    op.run = [f](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t) {
+        return aeth::fir_exec_on(f, s, have_hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout);
+    };
+    return AETH_OK;
+}
+
+int make_op(aeth_ctx *ctx, const aeth_stream_op *d, StageOp &op)
+{
+    AETH_REQUIRE(ctx && d, AETH_E_ARG, "null argument");
+    if (d->kind == AETH_STREAM_FIR) {
+        int rc = op_fir(d->fir, op); if (rc) return rc;
+        AETH_REQUIRE(op.ctx == ctx, AETH_E_ARG, "the filter belongs to another context");
+        return AETH_OK;
+    }
+    aeth_fft *p = d->fft;
+    AETH_REQUIRE(p, AETH_E_ARG, "plan is null");
+    AETH_REQUIRE(p->ctx == ctx, AETH_E_ARG, "the plan belongs to another context");
+    const size_t N = p->len;
+    op.ctx = ctx; op.align = N; op.out_per_align = N;
+    const aeth_stream_op c = *d;                     // by value: the descriptor need not outlive the call, but does anyway
+    switch (d->kind) {
+    case AETH_STREAM_FFT:                            // Fft::fwd / bwd over chunks_mut(fft_len) (src/util/plot.rs:59-61)
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t) {
+            return aeth_fft_exec(p, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout, cnt / N, c.sign, c.scale_kind_fwd, c.x_fwd);
+        };
+        return AETH_OK;
+    case AETH_STREAM_FFT_MUL_IFFT:                   // benches/benches.rs:410-416, in place
+        op.inplace = true;
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *, size_t) {
+            return aeth_fft_mul_ifft(p, (aeth_cf32 *)dc, cnt, cnt / N, c.sig_dev, c.n_sig, c.scale_kind_fwd, c.x_fwd, c.scale_kind_bwd, c.x_bwd);
+        };
+        return AETH_OK;
+    case AETH_STREAM_FFT_MUL_IFFT_DEMOD:             // ... then Modulation::demod_naive (examples/modem.rs:28-31)
+        AETH_REQUIRE(c.bits_per_symbol == 1 || c.bits_per_symbol == 2, AETH_E_UNSUPPORTED, "bits_per_symbol %d: BPSK (1) or QPSK (2)", c.bits_per_symbol);
+        op.out_unit = 1; op.out_per_align = N * (size_t)c.bits_per_symbol;
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out) {
+            return aeth_fft_mul_ifft_demod(p, (const aeth_cf32 *)dc, cnt, cnt / N, c.sig_dev, c.n_sig, c.scale_kind_fwd, c.x_fwd,
+                                           c.scale_kind_bwd, c.x_bwd, c.bits_per_symbol, c.table_host, (uint8_t *)dout, cnt_out, c.compat);
+        };
+        return AETH_OK;
+    case AETH_STREAM_FFT_INTERPOLATE:                // the transform, then sampling::interpolate per frame (BASELINE config 5)
+        op.out_per_align = N + (N - 1) * c.n_between;
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out) {
+            size_t wrote = 0;
+            int rc = aeth_fft_exec_interpolate(p, (const aeth_cf32 *)dc, cnt, cnt / N, c.sign, c.scale_kind_fwd, c.x_fwd, (aeth_cf32 *)dout,
+                                               cnt_out, c.n_between, c.compat, &wrote);
+            if (rc == AETH_OK && wrote != cnt_out) rc = aeth::set_error(AETH_E_LEN, "interpolate wrote %zu of %zu", wrote, cnt_out);
+            return rc;
+        };
+        return AETH_OK;
+    default:
+        return aeth::set_error(AETH_E_ARG, "unknown stream op %d", d->kind);
+    }
+}
+
+int stream_any(aeth_ctx *ctx, const aeth_stream_op *d, const void *in, size_t n_in, void *out, size_t n_out, size_t chunk,
+               aeth_pipe_stats *stats, aeth_pipe_util *util)
+{
+    StageOp op;
+    int rc = make_op(ctx, d, op); if (rc) return rc;
+    if (d->kind != AETH_STREAM_FIR)
+        AETH_REQUIRE(n_in % op.align == 0, AETH_E_LEN, AETH_MSG_FFT_LEN);             /* fft.rs:163-167: whole frames only */
+    return stream_host(op, nullptr, in, n_in, out, n_out, chunk, stats, util);
 }
 
 }  // namespace
 
 extern "C" {
 
+int aeth_stream_host(aeth_ctx *ctx, const aeth_stream_op *op, const void *in, size_t n_in, void *out, size_t n_out,
+                     size_t chunk, aeth_pipe_stats *stats)
+{
+    return stream_any(ctx, op, in, n_in, out, n_out, chunk, stats, nullptr);
+}
+
+int aeth_stream_host_util(aeth_ctx *ctx, const aeth_stream_op *op, const void *in, size_t n_in, void *out, size_t n_out,
+                          size_t chunk, aeth_pipe_util *util)
+{
+    AETH_REQUIRE(util, AETH_E_ARG, "util is null");
+    return stream_any(ctx, op, in, n_in, out, n_out, chunk, nullptr, util);
+}
+
+size_t aeth_stream_out_count(aeth_ctx *ctx, const aeth_stream_op *op, size_t n_in)
+{
+    StageOp so;
+    if (make_op(ctx, op, so) != AETH_OK) return 0;
+    return so.out_count(n_in);
+}
+
 int aeth_fir_stream_host(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_stats *stats)
 {
-    return fir_stream_host(f, nullptr, in, n, out, chunk, stats);
+    StageOp op;
+    int rc = op_fir(f, op); if (rc) return rc;
+    return stream_host(op, nullptr, in, n, out, n, chunk, stats);
 }
 
 int aeth_fir_stream_host_util(aeth_fir *f, const aeth_cf32 *in, size_t n, aeth_cf32 *out, size_t chunk, aeth_pipe_util *util)
 {
     AETH_REQUIRE(util, AETH_E_ARG, "util is null");
-    return fir_stream_host(f, nullptr, in, n, out, chunk, nullptr, util);
+    StageOp op;
+    int rc = op_fir(f, op); if (rc) return rc;
+    return stream_host(op, nullptr, in, n, out, n, chunk, nullptr, util);
 }
+
+/* Gives back what a context retains between calls: the host pipeline's stage streams, device slots, pinned staging
+ * pools and copy threads, and the device scratch of the host-slice flavours.  The next call that needs them creates
+ * them again. */
+int aeth_ctx_trim(aeth_ctx *ctx)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    aeth::DeviceGuard g(ctx->device);
+    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
+    aeth::pipe_release(ctx);
+    for (int i = 0; i < 2; i++)
+        if (ctx->stage[i]) { AETH_HIP(hipFree(ctx->stage[i])); ctx->stage[i] = nullptr; ctx->stage_bytes[i] = 0; }
+    return AETH_OK;
+}
+
+/* test hook (tests/test_gpu_pool.py): the n-th staging element taken from now on fails after it has been taken */
+void aeth_test_fail_staging_after(int n) { aeth::pipe_fail_arm(n); }
 
 }  // extern "C"

@@ -18,36 +18,20 @@
 
 #include <unistd.h>
 
-#include <algorithm>
-#include <cstring>
-#include <map>
-#include <mutex>
 #include <new>
-#include <vector>
 
+// The pool, the range registry and their locking live in aeth_hostcore.h (no HIP in there: that header also builds
+// under the thread and address sanitizers, tests/test_hostcore_sanitizers.py); this file supplies the pinned allocator
+// and the C ABI's argument checks and error texts.
 struct aeth_pool {
     int device = 0;                     // of the context it was made on (kept by value: a pool may outlive its context)
-    size_t elem_bytes = 0;
     int flags = 0;
-    std::mutex mu;                      // Pool<T> = Arc<Mutex<PoolInner<T>>> (pool.rs:71-73)
-    std::vector<void *> elems;          // checked-in elements (PoolInner.elems, :163)
-    std::vector<void *> owned;          // every element made so far; cap = owned.size() (PoolInner.cap, :171)
+    aeth::hostcore::PoolCore *core = nullptr;
 };
 
 namespace {
 
-// host ranges known to be page-locked: pool elements and explicit registrations.  [lo, hi) keyed by lo.
-struct Range { uintptr_t hi; int kind; };
-std::mutex g_mu;
-std::map<uintptr_t, Range> g_ranges;
-
-bool overlaps_locked(uintptr_t lo, uintptr_t hi)
-{
-    auto it = g_ranges.upper_bound(lo);                 // first range starting after lo
-    if (it != g_ranges.end() && it->first < hi) return true;
-    if (it != g_ranges.begin()) { --it; if (it->second.hi > lo) return true; }
-    return false;
-}
+namespace hc = aeth::hostcore;
 
 size_t page_size()
 {
@@ -55,58 +39,34 @@ size_t page_size()
     return p;
 }
 
-int pool_make_locked(aeth_pool *p, void **out)          // the `maker` (pool.rs:46,117): one pinned element
+// PinHooks over hipHostMalloc / hipHostFree; `user` is the pool (for its device)
+int pin_alloc(void *user, void **out, size_t bytes)
 {
-    aeth::DeviceGuard g(p->device);
-    void *h = nullptr;
-    AETH_HIP(hipHostMalloc(&h, p->elem_bytes, hipHostMallocPortable));
-    aeth::pinned_add(h, p->elem_bytes, aeth::PIN_POOL);
-    p->owned.push_back(h);
-    *out = h;
-    return AETH_OK;
+    aeth::DeviceGuard g(static_cast<aeth_pool *>(user)->device);
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    return e == hipSuccess ? 0 : aeth::hip_fail(e, "hipHostMalloc");
+}
+
+int pin_release(void *user, void *p)
+{
+    aeth::DeviceGuard g(static_cast<aeth_pool *>(user)->device);
+    const hipError_t e = hipHostFree(p);
+    return e == hipSuccess ? 0 : aeth::hip_fail(e, "hipHostFree");
 }
 
 }  // namespace
 
 namespace aeth {
 
-void pinned_add(const void *p, size_t bytes, int kind)
-{
-    std::lock_guard<std::mutex> l(g_mu);
-    g_ranges[(uintptr_t)p] = Range{(uintptr_t)p + bytes, kind};
-}
-
-void pinned_remove(const void *p)
-{
-    std::lock_guard<std::mutex> l(g_mu);
-    g_ranges.erase((uintptr_t)p);
-}
-
-bool host_range_pinned(const void *p, size_t bytes)
-{
-    if (!p || !bytes) return false;
-    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
-    std::lock_guard<std::mutex> l(g_mu);
-    auto it = g_ranges.upper_bound(lo);
-    if (it == g_ranges.begin()) return false;
-    --it;
-    return it->first <= lo && hi <= it->second.hi;      // wholly inside ONE known range
-}
+void pinned_add(const void *p, size_t bytes, int kind) { hc::ranges().add(p, bytes, kind); }
+void pinned_remove(const void *p) { hc::ranges().remove(p); }
+bool host_range_pinned(const void *p, size_t bytes) { return hc::ranges().contains(p, bytes); }
 
 int pool_destroy_forced(aeth_pool *p)
 {
     if (!p) return AETH_OK;
-    int rc = AETH_OK;
-    {
-        aeth::DeviceGuard g(p->device);
-        std::lock_guard<std::mutex> l(p->mu);
-        for (void *h : p->owned) {
-            pinned_remove(h);
-            const hipError_t e = hipHostFree(h);
-            if (e != hipSuccess && rc == AETH_OK) rc = hip_fail(e, "hipHostFree");
-        }
-        p->owned.clear(); p->elems.clear();
-    }
+    int rc = p->core ? p->core->release_all() : AETH_OK;
+    delete p->core;
     delete p;
     return rc;
 }
@@ -124,14 +84,12 @@ int aeth_pool_create(aeth_ctx *ctx, size_t elem_bytes, size_t initial_len, int f
     AETH_REQUIRE((flags & ~AETH_POOL_ZERO_ON_RETURN) == 0, AETH_E_ARG, "unknown pool flags %d", flags);
     aeth_pool *p = new (std::nothrow) aeth_pool();
     AETH_REQUIRE(p, AETH_E_NOMEM, "out of host memory");
-    p->device = ctx->device; p->elem_bytes = elem_bytes; p->flags = flags;
-    for (size_t i = 0; i < initial_len; i++) {
-        void *h = nullptr;
-        const int rc = pool_make_locked(p, &h);
-        if (rc) { aeth::pool_destroy_forced(p); return rc; }
-        if (flags & AETH_POOL_ZERO_ON_RETURN) memset(h, 0, elem_bytes);      /* the resetter runs on the initial elements too (:53-56) */
-        p->elems.push_back(h);
-    }
+    p->device = ctx->device; p->flags = flags;
+    hc::PinHooks hooks; hooks.alloc = pin_alloc; hooks.release = pin_release; hooks.user = p;
+    p->core = new (std::nothrow) hc::PoolCore(elem_bytes, (flags & AETH_POOL_ZERO_ON_RETURN) != 0, hooks);
+    if (!p->core) { delete p; return aeth::set_error(AETH_E_NOMEM, "out of host memory"); }
+    const int rc = p->core->prefill(initial_len);             /* the resetter runs on the initial elements too (:53-56) */
+    if (rc) { aeth::pool_destroy_forced(p); return rc; }
     *out = p;
     return AETH_OK;
 }
@@ -141,11 +99,8 @@ int aeth_pool_create(aeth_ctx *ctx, size_t elem_bytes, size_t initial_len, int f
 int aeth_pool_destroy(aeth_pool *pool)
 {
     if (!pool) return AETH_OK;
-    {
-        std::lock_guard<std::mutex> l(pool->mu);
-        AETH_REQUIRE(pool->elems.size() == pool->owned.size(), AETH_E_ARG, "%zu pool element(s) still checked out",
-                     pool->owned.size() - pool->elems.size());
-    }
+    const size_t out = pool->core->checked_out();
+    AETH_REQUIRE(out == 0, AETH_E_ARG, "%zu pool element(s) still checked out", out);
     return aeth::pool_destroy_forced(pool);
 }
 
@@ -153,10 +108,7 @@ int aeth_pool_destroy(aeth_pool *pool)
 int aeth_pool_take(aeth_pool *pool, void **buf)
 {
     AETH_REQUIRE(pool && buf, AETH_E_ARG, "null argument");
-    std::lock_guard<std::mutex> l(pool->mu);
-    if (pool->elems.empty()) { *buf = nullptr; return AETH_OK; }
-    *buf = pool->elems.back();
-    pool->elems.pop_back();
+    *buf = pool->core->take();
     return AETH_OK;
 }
 
@@ -164,43 +116,22 @@ int aeth_pool_take(aeth_pool *pool, void **buf)
 int aeth_pool_take_or_make(aeth_pool *pool, void **buf)
 {
     AETH_REQUIRE(pool && buf, AETH_E_ARG, "null argument");
-    *buf = nullptr;
-    std::lock_guard<std::mutex> l(pool->mu);
-    if (pool->elems.empty()) return pool_make_locked(pool, buf);
-    *buf = pool->elems.back();
-    pool->elems.pop_back();
-    return AETH_OK;
+    return pool->core->take_or_make(buf);
 }
 
 /* Elem::drop -> PoolInner::give_back, :175-208: reset, then back into the pool */
 int aeth_pool_give_back(aeth_pool *pool, void *buf)
 {
     AETH_REQUIRE(pool && buf, AETH_E_ARG, "null argument");
-    std::lock_guard<std::mutex> l(pool->mu);
-    AETH_REQUIRE(std::find(pool->owned.begin(), pool->owned.end(), buf) != pool->owned.end(), AETH_E_ARG,
-                 "pointer is not an element of this pool");
-    AETH_REQUIRE(std::find(pool->elems.begin(), pool->elems.end(), buf) == pool->elems.end(), AETH_E_ARG,
-                 "element given back twice");
-    if (pool->flags & AETH_POOL_ZERO_ON_RETURN) memset(buf, 0, pool->elem_bytes);
-    pool->elems.push_back(buf);
+    const int r = pool->core->give_back(buf);
+    AETH_REQUIRE(r != hc::PoolCore::NOT_ELEMENT, AETH_E_ARG, "pointer is not an element of this pool");
+    AETH_REQUIRE(r != hc::PoolCore::GIVEN_TWICE, AETH_E_ARG, "element given back twice");
     return AETH_OK;
 }
 
-size_t aeth_pool_len(aeth_pool *pool)               /* Pool::len, :138-140 */
-{
-    if (!pool) return 0;
-    std::lock_guard<std::mutex> l(pool->mu);
-    return pool->elems.size();
-}
-
-size_t aeth_pool_cap(aeth_pool *pool)               /* Pool::cap, :157-159 */
-{
-    if (!pool) return 0;
-    std::lock_guard<std::mutex> l(pool->mu);
-    return pool->owned.size();
-}
-
-size_t aeth_pool_elem_bytes(const aeth_pool *pool) { return pool ? pool->elem_bytes : 0; }
+size_t aeth_pool_len(aeth_pool *pool) { return pool ? pool->core->len() : 0; }               /* Pool::len, :138-140 */
+size_t aeth_pool_cap(aeth_pool *pool) { return pool ? pool->core->cap() : 0; }               /* Pool::cap, :157-159 */
+size_t aeth_pool_elem_bytes(const aeth_pool *pool) { return pool ? pool->core->elem_bytes() : 0; }
 
 /* Explicit opt-in: page-lock memory the caller owns so that the host pipeline copies from / to it directly.  Whole
  * pages only, and nothing that touches a range this library already knows; the caller keeps the memory alive and
@@ -211,31 +142,26 @@ int aeth_host_register(aeth_ctx *ctx, void *ptr, size_t bytes)
     const size_t pg = page_size();
     AETH_REQUIRE(((uintptr_t)ptr % pg) == 0 && (bytes % pg) == 0, AETH_E_ALIGN,
                  "range must start on a page boundary and cover whole pages (page size %zu)", pg);
-    {
-        std::lock_guard<std::mutex> l(g_mu);
-        AETH_REQUIRE(!overlaps_locked((uintptr_t)ptr, (uintptr_t)ptr + bytes), AETH_E_ARG,
-                     "range overlaps memory that is already registered or belongs to a pinned pool");
-    }
+    // check and claim under ONE lock (two threads cannot both pass the check with overlapping ranges); the claim is
+    // pending -- invisible to aeth_host_is_pinned and the pipeline -- until the runtime has locked the pages
+    AETH_REQUIRE(hc::ranges().try_claim(ptr, bytes, hc::PIN_REGISTERED), AETH_E_ARG,
+                 "range overlaps memory that is already registered or belongs to a pinned pool");
     aeth::DeviceGuard g(ctx->device);
-    AETH_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
-    aeth::pinned_add(ptr, bytes, aeth::PIN_REGISTERED);
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { hc::ranges().remove(ptr); return aeth::hip_fail(e, "hipHostRegister"); }
+    hc::ranges().confirm(ptr);
     return AETH_OK;
 }
 
 int aeth_host_unregister(aeth_ctx *ctx, void *ptr)
 {
     AETH_REQUIRE(ctx && ptr, AETH_E_ARG, "null argument");
-    {
-        std::lock_guard<std::mutex> l(g_mu);
-        auto it = g_ranges.find((uintptr_t)ptr);
-        AETH_REQUIRE(it != g_ranges.end() && it->second.kind == aeth::PIN_REGISTERED, AETH_E_ARG,
-                     "pointer was not registered with aeth_host_register");
-    }
+    AETH_REQUIRE(hc::ranges().kind_at(ptr) == hc::PIN_REGISTERED, AETH_E_ARG, "pointer was not registered with aeth_host_register");
     aeth::DeviceGuard g(ctx->device);
     // nothing of this context may still be copying from / to the range
     AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     AETH_HIP(hipHostUnregister(ptr));
-    aeth::pinned_remove(ptr);
+    hc::ranges().remove(ptr);
     return AETH_OK;
 }
 

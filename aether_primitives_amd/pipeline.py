@@ -1,0 +1,99 @@
+"""Host-resident streams through the device, stage by stage: the mirror of the reference's `pipeline` module
+(src/pipeline.rs:24-41 `add_stage`, :123-137 `new`, per-stage report :89-114) over `aeth_stream_host`.
+
+The reference builds a pipeline from closures; the device's compute stage is one of the library's ops instead
+(include/aether_hip.h, aeth_stream_op).  Copy-in, upload, download and copy-out are the other four stages."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .fft import Scale, SIGN_REF_FWD
+
+FIR, FFT, FFT_MUL_IFFT, FFT_MUL_IFFT_DEMOD, FFT_INTERPOLATE = range(5)
+
+
+class _Op(C.Structure):
+    # struct aeth_stream_op, field by field
+    _fields_ = [("kind", C.c_int), ("fir", C.c_void_p), ("fft", C.c_void_p), ("sig_dev", C.c_void_p), ("n_sig", C.c_size_t),
+                ("sign", C.c_int), ("scale_kind_fwd", C.c_int), ("x_fwd", C.c_float), ("scale_kind_bwd", C.c_int),
+                ("x_bwd", C.c_float), ("bits_per_symbol", C.c_int), ("table_host", C.c_void_p), ("compat", C.c_int),
+                ("n_between", C.c_size_t)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("seconds", "samples", "chunks", "pinned")]
+
+
+class _Util(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("seconds", "samples", "chunks", "pinned", "active_upload", "active_kernel",
+                                          "active_download", "active_copy_in", "active_copy_out")]
+
+
+class Stage:
+    """The compute stage of a host pipeline: an op descriptor plus whatever keeps its operands alive."""
+
+    def __init__(self, ctx, op, out_dtype, keep=()):
+        self.ctx, self.op, self.out_dtype, self._keep = ctx, op, out_dtype, keep
+
+    @staticmethod
+    def fir(f):
+        return Stage(f.ctx, _Op(kind=FIR, fir=f.h), np.complex64, (f,))
+
+    @staticmethod
+    def fft(plan, scale=Scale.NONE, sign=SIGN_REF_FWD):
+        """Fft::fwd / bwd over chunks_mut(fft_len) (src/util/plot.rs:59-61)"""
+        return Stage(plan.ctx, _Op(kind=FFT, fft=plan.h, sign=sign, scale_kind_fwd=scale.kind, x_fwd=scale.x), np.complex64, (plan,))
+
+    @staticmethod
+    def mul_chain(plan, sig, s_fwd=Scale.NONE, s_bwd=Scale.NONE):
+        """vec_rfft -> vec_mul(&sig) -> vec_rifft per frame (benches/benches.rs:410-416); sig is a DeviceVec"""
+        return Stage(plan.ctx, _Op(kind=FFT_MUL_IFFT, fft=plan.h, sig_dev=sig._p(), n_sig=sig.n, scale_kind_fwd=s_fwd.kind, x_fwd=s_fwd.x,
+                                   scale_kind_bwd=s_bwd.kind, x_bwd=s_bwd.x), np.complex64, (plan, sig))
+
+    @staticmethod
+    def correlate_demod(plan, sig, bits_per_symbol=2, table=None, compat=True, s_fwd=Scale.NONE, s_bwd=Scale.NONE):
+        """the chain, then Modulation::demod_naive (examples/modem.rs:28-31): bits_per_symbol bytes out per sample"""
+        tab = None if table is None else np.ascontiguousarray(table, dtype=np.complex64)
+        return Stage(plan.ctx, _Op(kind=FFT_MUL_IFFT_DEMOD, fft=plan.h, sig_dev=sig._p(), n_sig=sig.n, scale_kind_fwd=s_fwd.kind,
+                                   x_fwd=s_fwd.x, scale_kind_bwd=s_bwd.kind, x_bwd=s_bwd.x, bits_per_symbol=bits_per_symbol,
+                                   table_host=None if tab is None else tab.ctypes.data, compat=1 if compat else 0),
+                     np.uint8, (plan, sig, tab))
+
+    @staticmethod
+    def fft_interpolate(plan, n_between, scale=Scale.NONE, sign=SIGN_REF_FWD, compat_im=True):
+        """the transform, then sampling::interpolate per frame (src/sampling.rs:7-24; BASELINE config 5)"""
+        return Stage(plan.ctx, _Op(kind=FFT_INTERPOLATE, fft=plan.h, sign=sign, scale_kind_fwd=scale.kind, x_fwd=scale.x,
+                                   n_between=n_between, compat=1 if compat_im else 0), np.complex64, (plan,))
+
+    def out_count(self, n_in):
+        return _lib.load().aeth_stream_out_count(self.ctx.h, C.byref(self.op), n_in)
+
+
+_STAGE_NAMES = ("copy-in", "upload", "compute", "download", "copy-out")
+
+
+def run(stage, x, out=None, chunk=0, report=False):
+    """x (host cf32 array) through copy-in | upload | stage | download | copy-out; returns (out, stats).  report=True
+    adds the seconds each stage was active and `lines` in the format of the reference's report (pipeline.rs:101-108)."""
+    lib = _lib.load()
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    n_out = stage.out_count(x.size)
+    if out is None:
+        out = np.empty(n_out, stage.out_dtype)
+    assert out.dtype == stage.out_dtype and out.flags["C_CONTIGUOUS"]
+    if report:
+        u = _Util()
+        check(lib.aeth_stream_host_util(stage.ctx.h, C.byref(stage.op), x.ctypes.data_as(C.c_void_p), x.size,
+                                        out.ctypes.data_as(C.c_void_p), out.size, chunk, C.byref(u)))
+        st = {k: getattr(u, k) for k, _ in _Util._fields_}
+        act = (u.active_copy_in, u.active_upload, u.active_kernel, u.active_download, u.active_copy_out)
+        st["lines"] = [f"Stage: {name:15} : Processed {int(u.chunks)} in {u.seconds:3.3f}s ({u.chunks / u.seconds:9.2f}/s); "
+                       f"Utilisation: {a / u.seconds * 100.0:3.2f}%"
+                       for name, a in zip(_STAGE_NAMES, act) if not (name.startswith("copy") and a == 0)] if u.seconds > 0 else []
+        return out, st
+    s = _Stats()
+    check(lib.aeth_stream_host(stage.ctx.h, C.byref(stage.op), x.ctypes.data_as(C.c_void_p), x.size,
+                               out.ctypes.data_as(C.c_void_p), out.size, chunk, C.byref(s)))
+    return out, {k: getattr(s, k) for k, _ in _Stats._fields_}

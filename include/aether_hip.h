@@ -72,6 +72,19 @@ enum { AETH_SCALE_NONE = 0, AETH_SCALE_SN = 1, AETH_SCALE_N = 2, AETH_SCALE_X = 
  * exactly one place. */
 enum { AETH_SIGN_REF_FWD = +1, AETH_SIGN_REF_BWD = -1 };
 
+/* Tuning knobs.  The library reads these environment integers ONLY in a process started with AETH_TUNING=1; each
+ * chooses between behaviours that ship (measured routes and shapes that were not kept are not in the library at all:
+ * csrc/aeth_internal.h, lab_int):
+ *   AETH_FIR_GRID_FIRST    sixteenths of the resident grid for a fused-FIR launch that starts a chain or runs alone
+ *                          with the overlap lane on (default 16)
+ *   AETH_FIR_GRID_CHAINED  the same for a launch that runs beside its predecessor (default 12)
+ *   AETH_FIR_SPREAD        0 / 1: force the burst / spread form of the next-window prefetch (default: spread for a
+ *                          lone launch, burst beside another)
+ *   AETH_NT                0 / 1: force plain / non-temporal accesses on streamed operands (default: by size)
+ *   AETH_PIPE_THREADS      host copy threads of the stream pipeline (default: half the cores the process may use, 2..12)
+ *   AETH_PIPE_MIXED        1: a pageable input next to a pinned output downloads directly into the caller's memory
+ *                          (default 0: both sides staged -- the mixed form measured 2.4 x slower downloads)
+ *   AETH_SYNC_SPIN_US      how long aeth_ctx_sync polls both queues before it blocks (default 2000) */
 AETH_API const char *aeth_last_error(void);
 AETH_API int aeth_version(void);                     /* 0x00MMmmpp */
 AETH_API int aeth_device_count(int *count);
@@ -212,7 +225,10 @@ AETH_API size_t aeth_fir_ntaps(const aeth_fir *fir);
 AETH_API size_t aeth_fir_fft_len(const aeth_fir *fir);
 AETH_API size_t aeth_fir_hop(const aeth_fir *fir);      /* outputs per block (<= fft_len-ntaps+1) */
 /* n outputs for n inputs.  hist_dev: NULL => zero initial state, else the
- * ntaps-1 samples preceding in_dev[0] (x[-(ntaps-1)] .. x[-1]).  out != in. */
+ * ntaps-1 samples preceding in_dev[0] (x[-(ntaps-1)] .. x[-1]).  The output range must not touch the input range
+ * or the history (AETH_E_ARG): blocks run concurrently and read windows that reach into their neighbours', so ANY
+ * overlap -- not only out == in -- would read samples already overwritten.  (Rust's &[T] / &mut [T] make that
+ * unrepresentable on the reference side; the C ABI has to refuse it.) */
 AETH_API int aeth_fir_exec(aeth_fir *fir, const aeth_cf32 *hist_dev, const aeth_cf32 *in_dev,
                            size_t n, aeth_cf32 *out_dev);
 /* The filter followed by sampling::downsample (src/sampling.rs:28-42) in one pass: out[i] = y[i * dec] with
@@ -246,26 +262,72 @@ AETH_API int aeth_host_register(aeth_ctx *ctx, void *ptr, size_t bytes);
 AETH_API int aeth_host_unregister(aeth_ctx *ctx, void *ptr);
 AETH_API int aeth_host_is_pinned(const void *ptr, size_t bytes);        /* 1: inside one pool element / registered range */
 
-/* Host-resident stream through the device at PCIe rate (SURVEY 8f "next" #4): hop-aligned chunks through five
- * stages -- copy-in (caller slice -> pinned pool element, host threads) | upload | kernel | download (three HIP
- * streams, three device slots handed on by events) | copy-out (host threads) -- so that both copy engines run back to
- * back: the counterpart of the reference's thread-per-stage pipeline over pooled buffers (src/pipeline.rs:52-137,
- * src/pool.rs:43-221).  A side that is already page-locked (aeth_host_is_pinned: a pool element, a registered range)
- * skips its host stage and is copied from / to directly.  Caller memory is never registered by this call.  Output is
- * bit-identical to aeth_fir_exec_host on the whole slice.  chunk_samples = 0 picks 4 Mi samples (an eighth of the
- * stream if that is less, at least 128 Ki).  stats may be NULL; stats->pinned = 1 * (in direct) + 2 * (out direct); an
- * input that needs staging takes the output through the host stage as well (measured: the mixed form is the slow one). */
+/* Host-resident stream through the device at PCIe rate (SURVEY 8f "next" #4): chunks through five stages -- copy-in
+ * (caller slice -> pinned pool element, host threads) | upload | compute | download (three HIP streams, three device
+ * slots handed on by events) | copy-out (host threads) -- so that both copy engines run back to back: the counterpart
+ * of the reference's thread-per-stage pipeline over pooled buffers (src/pipeline.rs:52-137, src/pool.rs:43-221).
+ *
+ * The reference's pipeline takes any closure as a stage (src/pipeline.rs:24-41 `add_stage<F: FnMut(O) -> U>`,
+ * :123-137 `new`); a closure cannot cross this boundary (as for vec_mutate), so the compute stage is described by an
+ * aeth_stream_op: one of the library's device ops applied chunk by chunk.  Input and output differ per op:
+ *   AETH_STREAM_FIR                 fir                      n cf32 in -> n cf32 out (hop-aligned chunks; = aeth_fir_exec)
+ *   AETH_STREAM_FFT                 fft, sign, scale_kind_fwd / x_fwd          frames of len cf32 -> the same (= aeth_fft_exec)
+ *   AETH_STREAM_FFT_MUL_IFFT        fft, sig_dev, both scales                  frames -> frames (= aeth_fft_mul_ifft)
+ *   AETH_STREAM_FFT_MUL_IFFT_DEMOD  ... + bits_per_symbol, table_host, compat  8 B in -> bits_per_symbol BYTES out per sample
+ *   AETH_STREAM_FFT_INTERPOLATE     fft, sign, scale, n_between, compat (= compat_im)   len in -> len + (len-1)*n_between out per frame
+ * Every op's output is bit-identical to its device flavour on the whole slice.  n_in counts input samples, n_out
+ * output ELEMENTS of the op's type and must equal aeth_stream_out_count(ctx, op, n_in) (AETH_E_LEN otherwise; the frame
+ * ops need whole frames: "Input and FFT must be the same length").  The two host ranges must not overlap (AETH_E_ARG).
+ *
+ * A side that is already page-locked (aeth_host_is_pinned: a pool element, a registered range) skips its host stage
+ * and is copied from / to directly; caller memory is never registered by these calls.  stats->pinned = 1 * (in direct)
+ * + 2 * (out direct); an input that needs staging takes the output through the host stage as well (measured: the
+ * mixed form is the slow one; AETH_PIPE_MIXED below).  chunk_samples = 0 picks 32 MiB on the larger side per chunk
+ * (an eighth of a short stream, at least 1 MiB), rounded to whole hops / frames.
+ *
+ * What a context keeps between calls: the three stage streams, three device slots per side, three pinned staging
+ * elements per side (only for pageable caller memory) and the copy threads, sized by the largest chunk seen.  A slot is
+ * at most 64 MiB (a larger chunk_samples is split internally; one frame of more than that still gets its slot), so the
+ * retained memory is bounded by 6 x 64 MiB of device memory and 6 x 64 MiB of pinned memory; aeth_ctx_trim gives all
+ * of it back (and the device scratch of the host-slice flavours), aeth_ctx_destroy does the same. */
 typedef struct { double seconds, samples, chunks, pinned; } aeth_pipe_stats;
-AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
-                                  size_t chunk_samples, aeth_pipe_stats *stats);
+enum { AETH_STREAM_FIR = 0, AETH_STREAM_FFT = 1, AETH_STREAM_FFT_MUL_IFFT = 2, AETH_STREAM_FFT_MUL_IFFT_DEMOD = 3,
+       AETH_STREAM_FFT_INTERPOLATE = 4 };
+typedef struct aeth_stream_op {
+    int kind;                          /* AETH_STREAM_*                                                          */
+    aeth_fir *fir;                     /* FIR                                                                    */
+    aeth_fft *fft;                     /* the frame ops: frames of aeth_fft_len(fft) samples                     */
+    const aeth_cf32 *sig_dev;          /* MUL_IFFT, MUL_IFFT_DEMOD: the multiplier, DEVICE memory, n_sig = len   */
+    size_t n_sig;
+    int sign;                          /* FFT, FFT_INTERPOLATE: AETH_SIGN_REF_FWD / _BWD                         */
+    int scale_kind_fwd; float x_fwd;   /* Scale of the (forward) transform                                       */
+    int scale_kind_bwd; float x_bwd;   /* MUL_IFFT, MUL_IFFT_DEMOD: Scale of the way back                        */
+    int bits_per_symbol;               /* MUL_IFFT_DEMOD: 1 (BPSK) or 2 (QPSK)                                   */
+    const aeth_cf32 *table_host;       /*   symbol table (host), NULL = the generic tables                       */
+    int compat;                        /*   as aeth_demod_naive; FFT_INTERPOLATE: compat_im of aeth_interpolate  */
+    size_t n_between;                  /* FFT_INTERPOLATE                                                        */
+} aeth_stream_op;
+AETH_API size_t aeth_stream_out_count(aeth_ctx *ctx, const aeth_stream_op *op, size_t n_in);   /* 0 for a bad op */
+AETH_API int aeth_stream_host(aeth_ctx *ctx, const aeth_stream_op *op, const void *in_host, size_t n_in,
+                              void *out_host, size_t n_out, size_t chunk_samples, aeth_pipe_stats *stats);
 /* The same run with the per-stage report of the reference's pipeline (src/pipeline.rs:89-114: items processed, rate and
- * "Utilisation" = time active / time elapsed, per stage): seconds each of the stages was busy -- upload, kernel, download
+ * "Utilisation" = time active / time elapsed, per stage): seconds each of the stages was busy -- upload, compute, download
  * from timed events around every stage operation, the two host stages from the wall clock between hand-over and completion
  * of each chunk.  Utilisation of a stage = active_x / seconds. */
 typedef struct { double seconds, samples, chunks, pinned, active_upload, active_kernel, active_download,
                  active_copy_in, active_copy_out; /* the two host stages (0 for a side copied directly) */ } aeth_pipe_util;
+AETH_API int aeth_stream_host_util(aeth_ctx *ctx, const aeth_stream_op *op, const void *in_host, size_t n_in,
+                                   void *out_host, size_t n_out, size_t chunk_samples, aeth_pipe_util *util);
+/* AETH_STREAM_FIR with the filter as the only argument (output bit-identical to aeth_fir_exec_host on the whole slice) */
+AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
+                                  size_t chunk_samples, aeth_pipe_stats *stats);
 AETH_API int aeth_fir_stream_host_util(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
                                        size_t chunk_samples, aeth_pipe_util *util);
+/* Releases what the context retains between calls (see above); the next call that needs it creates it again. */
+AETH_API int aeth_ctx_trim(aeth_ctx *ctx);
+/* Test support (tests/test_gpu_pool.py): the n-th pinned staging element the pipeline takes from now on fails right
+ * after it has been taken (once), so that the give-back of every error path can be checked. */
+AETH_API void aeth_test_fail_staging_after(int n);
 
 /* ---- raw sample files (SURVEY 8f "next" #3): src/util/file.rs:12-107 ------------------------ */
 /* The reference's binary files are header-less native-endian dumps of back-to-back structs;

@@ -21,6 +21,13 @@ SIGN_REF_FWD, SIGN_REF_BWD = +1, -1
 
 
 def build(force=False):
+    # AETH_ORACLE_SO: load this build of the same sources instead (the sanitizer build of `make -C oracle asan`,
+    # tests/test_hostcore_sanitizers.py); nothing is rebuilt then
+    global _SO
+    alt = os.environ.get("AETH_ORACLE_SO")
+    if alt:
+        _SO = alt
+        return _SO
     srcs = [os.path.join(_HERE, f) for f in ("aeth_oracle.c", "aeth_oracle.h", "fft_template.inc", "awgn_restatement.inc")]
     have_src = all(os.path.exists(s) for s in srcs)
     stale = (not os.path.exists(_SO)) or (

@@ -12,6 +12,18 @@ pub const AETH_POOL_ZERO_ON_RETURN: c_int = 1;
 /// aeth_pipe_stats: what the three-stage host-stream pipeline reports
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct aeth_pipe_stats { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64 }
+/// aeth_stream_op: the compute stage of the host pipeline (src/pipeline.rs:24-41 takes a closure; a closure cannot
+/// cross the C ABI, so the stage is one of the library's device ops, described field by field as in aether_hip.h)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct aeth_stream_op { pub kind: c_int, pub fir: *mut aeth_fir, pub fft: *mut aeth_fft, pub sig_dev: *const cf32, pub n_sig: usize,
+                            pub sign: c_int, pub scale_kind_fwd: c_int, pub x_fwd: c_float, pub scale_kind_bwd: c_int, pub x_bwd: c_float,
+                            pub bits_per_symbol: c_int, pub table_host: *const cf32, pub compat: c_int, pub n_between: usize }
+pub const AETH_STREAM_FIR: c_int = 0;
+pub const AETH_STREAM_FFT: c_int = 1;
+pub const AETH_STREAM_FFT_MUL_IFFT: c_int = 2;
+pub const AETH_STREAM_FFT_MUL_IFFT_DEMOD: c_int = 3;
+pub const AETH_STREAM_FFT_INTERPOLATE: c_int = 4;
 /// aeth_pipe_util: the same plus the seconds each stage (upload, kernel, download) was active -- the per-stage
 /// utilisation report of src/pipeline.rs:89-114
 #[repr(C)]
@@ -121,6 +133,13 @@ extern "C" {
     pub fn aeth_host_register(ctx: *mut aeth_ctx, ptr: *mut c_void, bytes: usize) -> c_int;
     pub fn aeth_host_unregister(ctx: *mut aeth_ctx, ptr: *mut c_void) -> c_int;
     pub fn aeth_host_is_pinned(ptr: *const c_void, bytes: usize) -> c_int;
+    pub fn aeth_stream_out_count(ctx: *mut aeth_ctx, op: *const aeth_stream_op, n_in: usize) -> usize;
+    pub fn aeth_stream_host(ctx: *mut aeth_ctx, op: *const aeth_stream_op, inp: *const c_void, n_in: usize, out: *mut c_void,
+                            n_out: usize, chunk: usize, stats: *mut aeth_pipe_stats) -> c_int;
+    pub fn aeth_stream_host_util(ctx: *mut aeth_ctx, op: *const aeth_stream_op, inp: *const c_void, n_in: usize, out: *mut c_void,
+                                 n_out: usize, chunk: usize, util: *mut aeth_pipe_util) -> c_int;
+    pub fn aeth_ctx_trim(ctx: *mut aeth_ctx) -> c_int;
+    pub fn aeth_test_fail_staging_after(n: c_int);
     pub fn aeth_fir_stream_host(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,
                                 stats: *mut aeth_pipe_stats) -> c_int;
     pub fn aeth_fir_stream_host_util(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,

@@ -122,6 +122,28 @@ def test_fir_rejects_in_place(ctx, taps):
         f.filter(d, out=d)
 
 
+def test_fir_rejects_any_overlap_of_output_and_input(ctx, taps):
+    """not only out == in: blocks run concurrently and read windows their neighbours may already have overwritten, so a
+    partially overlapping output (out = in + 100) is refused too -- and an output that touches the history, and the
+    same for the decimating flavour.  Adjacent ranges (out starts where in ends) are fine."""
+    f = Fir(ctx, taps, 2048)
+    n = 6000
+    big = ctx.vec(rand_c64(2, 3 * n))
+    x = big.slice(0, n)
+    for lo in (100, n - 1, 1):
+        with pytest.raises(ap.AetherError, match="overlaps"):
+            f.filter(x, out=big.slice(lo, lo + n))
+    with pytest.raises(ap.AetherError, match="overlaps"):
+        f.filter(big.slice(100, 100 + n), out=big.slice(0, n))          # out in front of in, reaching into it
+    hist = big.slice(2 * n, 2 * n + 63)
+    with pytest.raises(ap.AetherError, match="overlaps"):
+        f.filter(x, out=big.slice(2 * n - n + 40, 2 * n + 40), hist=hist)   # out ends inside the history
+    with pytest.raises(ap.AetherError, match="overlaps"):
+        f.filter_decim(x, 4, out=big.slice(n - 10, n - 10 + n // 4))
+    y = f.filter(x, out=big.slice(n, 2 * n))                            # adjacent: allowed
+    assert bits_equal(y.to_host(), f.filter(x).to_host())
+
+
 def test_c3_full_size(ctx, oracle, taps):
     """BASELINE config 3: 64 taps over 16 M samples (8456 blocks of 1984)."""
     n = 1 << 24

@@ -1,0 +1,177 @@
+"""GPU parity: the host pipeline with a generic compute stage (src/pipeline.rs:24-41 `add_stage`, :123-137 `new`).
+
+Every op the stage can be -- FIR, batched FFT frames, the correlator chain, correlate + demod (8 B in, 2 B out),
+FFT + interpolate (1 in, 10 out) -- streamed from HOST memory chunk by chunk must give exactly the bits of its device
+flavour on the whole slice: pageable memory (staged through the context's pinned pools), pool elements (direct) and
+chunk sizes that do and do not divide the stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import aether_primitives_amd as ap
+from aether_primitives_amd import Scale, HipFft, Fir, modulation, pipeline, pool, sampling
+from helpers import bits_equal, rand_c64
+
+pytestmark = pytest.mark.gpu
+N = 2048
+
+
+@pytest.fixture(scope="module")
+def plan(ctx):
+    return HipFft(ctx, N, max_batch=64)
+
+
+@pytest.fixture(scope="module")
+def sig(ctx):
+    return ctx.vec(rand_c64(5, N, scale=0.3))
+
+
+@pytest.mark.parametrize("frames,chunk", [(1, 0), (37, 0), (37, N * 5), (600, 0), (600, N * 64)])
+def test_fft_frames_stream(ctx, plan, frames, chunk):
+    x = rand_c64(frames, frames * N)
+    want = ctx.vec(x)
+    plan.ifwd(want, Scale.SN)
+    y, st = pipeline.run(pipeline.Stage.fft(plan, Scale.SN), x, chunk=chunk)
+    assert bits_equal(y, want.to_host()) and st["samples"] == x.size
+    if chunk:
+        assert st["chunks"] == -(-x.size // chunk)
+
+
+@pytest.mark.parametrize("frames,chunk", [(3, 0), (200, N * 33)])
+def test_correlator_chain_stream_runs_in_place_on_the_slot(ctx, plan, sig, frames, chunk):
+    x = rand_c64(100 + frames, frames * N)
+    want = ctx.vec(x)
+    plan.mul_chain(want, sig)
+    y, _ = pipeline.run(pipeline.Stage.mul_chain(plan, sig), x, chunk=chunk)
+    assert bits_equal(y, want.to_host())
+    y2, st = pipeline.run(pipeline.Stage.mul_chain(plan, sig, Scale.SN, Scale.SN), x, chunk=chunk, report=True)
+    want = ctx.vec(x)
+    plan.mul_chain(want, sig, Scale.SN, Scale.SN)
+    assert bits_equal(y2, want.to_host()) and len(st["lines"]) == 5 and "compute" in st["lines"][2]
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+@pytest.mark.parametrize("frames,chunk", [(5, 0), (300, N * 40)])
+def test_correlate_demod_stream_8_bytes_in_bits_out(ctx, plan, sig, bps, frames, chunk):
+    x = rand_c64(7 * bps + frames, frames * N)
+    q = modulation.qpsk(ctx) if bps == 2 else modulation.bpsk(ctx)
+    want = q.correlate_demod(plan, ctx.vec(x), sig).to_host()
+    y, st = pipeline.run(pipeline.Stage.correlate_demod(plan, sig, bps), x, chunk=chunk)
+    assert y.dtype == np.uint8 and y.size == bps * x.size and np.array_equal(y, want)
+
+
+def test_correlate_demod_stream_custom_table(ctx, plan, sig):
+    x = rand_c64(77, 20 * N)
+    tab = np.array([0.5 + 1j, -1 + 0.25j, 0.75 - 1j, -0.5 - 0.5j], np.complex64)       # not separable
+    q = modulation.table(ctx, tab)
+    want = q.correlate_demod(plan, ctx.vec(x), sig, compat=False).to_host()
+    y, _ = pipeline.run(pipeline.Stage.correlate_demod(plan, sig, 2, table=tab, compat=False), x, chunk=N * 7)
+    assert np.array_equal(y, want)
+
+
+@pytest.mark.parametrize("n,nb,frames,chunk", [(2048, 9, 40, 0), (2048, 9, 40, 2048 * 7), (4096, 3, 9, 4096 * 2), (65536, 9, 6, 65536 * 4)])
+def test_fft_interpolate_stream_one_in_ten_out(ctx, n, nb, frames, chunk):
+    p = HipFft(ctx, n, max_batch=frames)
+    x = rand_c64(n + nb, frames * n)
+    out_len = (n + (n - 1) * nb) * frames
+    want = ctx.empty(out_len)
+    p.rfft_interpolate(ctx.vec(x), want, nb, Scale.SN)
+    st = pipeline.Stage.fft_interpolate(p, nb, Scale.SN)
+    assert st.out_count(x.size) == out_len
+    y, s = pipeline.run(st, x, chunk=chunk)
+    assert y.size == out_len and bits_equal(y, want.to_host())
+
+
+def test_fir_through_the_generic_entry_point(ctx):
+    f = Fir(ctx, rand_c64(1, 64, scale=0.2), 2048)
+    x = rand_c64(11, 1984 * 70 + 5)
+    y, _ = pipeline.run(pipeline.Stage.fir(f), x, chunk=1984 * 16)
+    assert bits_equal(y, f.filter(x)) and bits_equal(y, f.filter_stream(x)[0])
+
+
+def test_stream_from_and_into_pool_elements(ctx, plan, sig):
+    """pinned on both sides: no host stage (stats: pinned == 3); the demodulator's byte output lands in a pool element"""
+    frames = 64
+    x = rand_c64(3, frames * N)
+    p = pool.Pool(ctx, x.nbytes, initial_len=2)
+    with p.take() as ein, p.take() as eout:
+        xin = ein.array(np.complex64)
+        xin[:] = x
+        bits = eout.array(np.uint8)[: 2 * x.size]
+        _, st = pipeline.run(pipeline.Stage.correlate_demod(plan, sig, 2), xin, out=bits, chunk=N * 10)
+        want = modulation.qpsk(ctx).correlate_demod(plan, ctx.vec(x), sig).to_host()
+        assert st["pinned"] == 3 and np.array_equal(bits, want)
+    p.close()
+
+
+def test_stream_argument_errors(ctx, plan, sig):
+    lib = plan._lib
+    x = rand_c64(1, 3 * N + 1)                                            # not whole frames
+    with pytest.raises(ap.AetherError, match="Input and FFT must be the same length"):
+        pipeline.run(pipeline.Stage.fft(plan), x, out=np.empty(3 * N + 1, np.complex64))
+    x = rand_c64(1, 3 * N)
+    with pytest.raises(ap.LengthMismatch):
+        pipeline.run(pipeline.Stage.fft(plan), x, out=np.empty(3 * N - 1, np.complex64))
+    buf = np.zeros(4 * N, np.complex64)
+    with pytest.raises(ap.AetherError, match="overlap"):                   # out starts inside in
+        pipeline.run(pipeline.Stage.fft(plan), buf[: 3 * N], out=buf[N:])
+    other = ap.Context(0)
+    with pytest.raises(ap.AetherError, match="another context"):
+        st = pipeline.Stage.fft(plan); st.ctx = other
+        pipeline.run(st, x)
+    other.close()
+    bad = pipeline.Stage.fft(plan); bad.op.kind = 17
+    assert bad.out_count(N) == 0
+    del lib
+
+
+def test_a_failed_staging_take_leaves_nothing_checked_out():
+    """every error path of the staging take gives its elements back: after a forced failure the next, LARGER run (which
+    has to destroy and rebuild the staging pools) still works -- round 3 left them checked out and the pool refused"""
+    c = ap.Context(0)
+    f = Fir(c, rand_c64(1, 64, scale=0.2), 2048)
+    x = rand_c64(2, 1984 * 30)
+    want = f.filter(x)
+    lib = f._lib
+    for nth in (1, 2, 3, 4, 5, 6):                                          # 3 input + 3 output elements per run
+        lib.aeth_test_fail_staging_after(nth)
+        with pytest.raises(ap.AetherError, match="forced failure"):
+            f.filter_stream(x, chunk=1984 * 10)
+        y, _ = f.filter_stream(x, chunk=1984 * 10)
+        assert bits_equal(y, want)
+    big = rand_c64(3, 1984 * 300)
+    y, _ = f.filter_stream(big, chunk=1984 * 100)                          # larger elements: the pools are rebuilt
+    assert bits_equal(y, f.filter(big))
+    lib.aeth_test_fail_staging_after(0)
+    c.close()
+
+
+def test_trim_gives_back_and_the_next_run_rebuilds(ctx, plan):
+    free0 = _free_bytes()
+    x = rand_c64(4, 512 * N)
+    want, _ = pipeline.run(pipeline.Stage.fft(plan, Scale.SN), x)
+    held = free0 - _free_bytes()
+    ctx.trim()
+    assert _free_bytes() >= free0 - (1 << 20) or held == 0                 # the slots went back to the device
+    again, _ = pipeline.run(pipeline.Stage.fft(plan, Scale.SN), x)
+    assert bits_equal(again, want)
+    ctx.trim()
+
+
+def test_a_huge_chunk_is_split_so_that_a_slot_stays_bounded(ctx, plan):
+    """chunk_samples beyond 64 MiB per slot is split internally: what the context retains stays bounded"""
+    frames = (80 << 20) // (N * 8)                                          # an 80 MiB stream asked for as ONE chunk
+    x = rand_c64(9, frames * N)
+    y, st = pipeline.run(pipeline.Stage.fft(plan, Scale.NONE), x, chunk=x.size)
+    assert st["chunks"] == 2
+    want = ctx.vec(x); plan.ifwd(want, Scale.NONE)
+    assert bits_equal(y, want.to_host())
+    ctx.trim()
+
+
+def _free_bytes():
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
