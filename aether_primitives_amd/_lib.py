@@ -118,6 +118,7 @@ PROTOTYPES = {
     "aeth_awgn_apply": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
     "aeth_awgn_fill": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
     "aeth_rng_philox4x32_10": (i32, [vp, vp, sz, vp]),
+    "aeth_rng_philox4x32": (i32, [vp, vp, sz, i32, vp]),
 }
 
 _lib = None

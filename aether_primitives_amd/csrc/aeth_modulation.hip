@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void modulate_awgn_kernel(const uint8_t *__
     if ((offset & 1) == 0) {
         uint32_t w[4];
         const uint64_t call = (offset + i0) >> 1;
-        aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        aeth_rng_draw(call, seed, w);
         aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
         aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
     } else {

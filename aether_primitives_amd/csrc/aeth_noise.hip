@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__
     if ((offset & 1) == 0) {
         uint32_t w[4];
         const uint64_t call = (offset + i0) >> 1;
-        aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        aeth_rng_draw(call, seed, w);
         aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
         aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
     } else {
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void awgn_fill_kernel(float2 *__restrict__ 
     if ((offset & 1) == 0) {
         uint32_t w[4];
         const uint64_t call = (offset + i0) >> 1;
-        aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        aeth_rng_draw(call, seed, w);
         aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
         aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
     } else {
@@ -85,13 +85,14 @@ __global__ __launch_bounds__(kBlock) void awgn_fill_kernel(float2 *__restrict__ 
     }
 }
 
-// the generator's integer stage on its own: out[i] = Philox4x32-10(counter = in[i][0..3], key = in[i][4..5])
+// the generator's integer stage on its own: out[i] = Philox4x32-R(counter = in[i][0..3], key = in[i][4..5])
+template <int R>
 __global__ __launch_bounds__(kBlock) void philox_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     uint32_t w[4];
-    aeth_philox4x32_10(in[6 * i], in[6 * i + 1], in[6 * i + 2], in[6 * i + 3], in[6 * i + 4], in[6 * i + 5], w);
+    aeth_philox4x32(R, in[6 * i], in[6 * i + 1], in[6 * i + 2], in[6 * i + 3], in[6 * i + 4], in[6 * i + 5], w);
     out[4 * i] = w[0]; out[4 * i + 1] = w[1]; out[4 * i + 2] = w[2]; out[4 * i + 3] = w[3];
 }
 
@@ -116,16 +117,22 @@ int aeth_awgn_fill(aeth_ctx *ctx, aeth_cf32 *target, size_t n, float power, uint
     return AETH_OK;
 }
 
-int aeth_rng_philox4x32_10(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, uint32_t *out_dev)
+int aeth_rng_philox4x32(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, int rounds, uint32_t *out_dev)
 {
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    AETH_REQUIRE(rounds == 7 || rounds == 10, AETH_E_UNSUPPORTED, "Philox4x32-%d: 7 (the generator's) or 10 rounds", rounds);
     if (n == 0) return AETH_OK;
     AETH_REQUIRE(ctr_key_dev && out_dev, AETH_E_ARG, "null pointer");
     aeth::DeviceGuard dev_guard(ctx->device);
-    hipLaunchKernelGGL(philox_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
-                       ctr_key_dev, out_dev, n);
+    auto kern = rounds == 7 ? philox_kernel<7> : philox_kernel<10>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx), ctr_key_dev, out_dev, n);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
+}
+
+int aeth_rng_philox4x32_10(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, uint32_t *out_dev)
+{
+    return aeth_rng_philox4x32(ctx, ctr_key_dev, n, 10, out_dev);
 }
 
 int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal, size_t n, float power, uint64_t seed, uint64_t offset)

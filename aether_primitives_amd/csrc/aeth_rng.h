@@ -1,5 +1,5 @@
 // aeth_rng.h -- counter-based complex normal generator used by the AWGN kernel.
-// Plain C, integer + f32 (+,-,*,/,sqrt, explicit fmaf) only, fixed operation order: compiled with
+// Plain C, integer + f32 (+,-,*,sqrt, explicit fmaf) only, fixed operation order: compiled with
 // -ffp-contract=off it is bit-reproducible between host compilers and the GPU.
 #pragma once
 #include <math.h>
@@ -10,19 +10,25 @@
 
 /* ---- counter-based complex normal generator (the BUILD's own; the reference's
  * StdRng + rand_distr::Normal stream, src/noise.rs:2-4,29-44, cannot be reproduced).
- * Philox4x32-10 keyed by the seed, counter = pair index; one call -> four 32-bit words ->
- * two complex samples by Box-Muller.  Every floating-point step is +, -, *, /, sqrt or an
+ * Philox4x32-7 keyed by the seed, counter = pair index; one call -> four 32-bit words ->
+ * two complex samples by Box-Muller.  Every floating-point step is +, -, *, sqrt or an
  * EXPLICIT fmaf (correctly rounded by definition, one instruction on the GPU) on f32 in a fixed
- * order -- no transcendental libm call -- so CPU oracle and GPU kernel agree bit for bit when
- * both are compiled without implicit contraction.  (Round 3: the polynomial steps became fmaf and
- * the quadrant selection branch-free; the generator's low-order bits changed with that.) ---- */
-AETH_RNG_FN void aeth_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                    uint32_t out[4])
+ * order -- no division, no transcendental libm call -- so CPU oracle and GPU kernel agree bit for
+ * bit when both are compiled without implicit contraction.
+ * History: round 3 made the polynomial steps fmaf and the quadrant selection branch-free; round 4
+ * went from ten Philox rounds to SEVEN (Salmon et al., SC'11, table 2: Philox4x32-7 is the smallest
+ * round count of this width that passes BigCrush -- ten is the authors' safety margin, not the
+ * reference's choice: the reference draws from rand's StdRng) and from ln m = 2 atanh((m-1)/(m+1))
+ * with its f32 division to a division-free polynomial in m - 1.  The sample values changed with
+ * each step; the integer stage is pinned for BOTH round counts by the Random123 known answers. ---- */
+#define AETH_RNG_ROUNDS 7
+AETH_RNG_FN void aeth_philox4x32(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                 uint32_t out[4])
 {
 #if defined(__clang__)
 #pragma unroll
 #endif
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds; r++) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -31,9 +37,16 @@ AETH_RNG_FN void aeth_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint3
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+/* the generator's draw: counter = (call, 0), key = seed */
+AETH_RNG_FN void aeth_rng_draw(uint64_t call, uint64_t seed, uint32_t out[4])
+{
+    aeth_philox4x32(AETH_RNG_ROUNDS, (uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), out);
+}
 
-/* natural log of u in (0, 1], |error| ~ 1e-7 relative: u = m * 2^e, m in [sqrt(.5), sqrt(2)),
- * ln m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^9 */
+/* natural log of u in (0, 1], ~1 ulp: u = m * 2^e, m in [sqrt(.5), sqrt(2)), f = m - 1,
+ *     ln m = f - f^2/2 + f^3 P(f),   P of degree 8 (the single-precision coefficients of Cephes' logf, S. Moshier),
+ *     ln u = ln m + e ln 2 with ln 2 split into 0.693359375 - 2.12194440e-4 so that e * hi is exact.
+ * No division: the atanh form this replaces spent a third of its instructions on (m - 1) / (m + 1). */
 AETH_RNG_FN float aeth_rng_log(float u)
 {
     union { float f; uint32_t i; } v; v.f = u;
@@ -43,14 +56,20 @@ AETH_RNG_FN float aeth_rng_log(float u)
     const int hi = m > 1.41421356f;                         /* fold [sqrt 2, 2) onto [sqrt .5, 1) */
     m = hi ? m * 0.5f : m;
     e += hi;
-    const float s = (m - 1.0f) / (m + 1.0f);
-    const float s2 = s * s;
-    float p = 0.11111111f;                                  /* 1/9 */
-    p = fmaf(p, s2, 0.14285715f);                           /* 1/7 */
-    p = fmaf(p, s2, 0.2f);
-    p = fmaf(p, s2, 0.33333334f);
-    p = fmaf(p, s2, 1.0f);
-    return fmaf((float)e, 0.69314718f, (2.0f * s) * p);
+    const float f = m - 1.0f, z = f * f, fe = (float)e;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (p * f) * z;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(fe, 0.693359375f, f + y);
 }
 
 /* (cos, sin)(2 pi w / 2^24), w a 24-bit integer: quadrant by the top two bits, then
@@ -98,7 +117,7 @@ AETH_RNG_FN void aeth_rng_cnormal(uint64_t seed, uint64_t idx, float *re, float 
 {
     uint32_t w[4];
     const uint64_t call = idx >> 1;
-    aeth_philox4x32_10((uint32_t)call, (uint32_t)(call >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    aeth_rng_draw(call, seed, w);
     if (idx & 1) aeth_rng_normal_pair(w[2], w[3], re, im);
     else aeth_rng_normal_pair(w[0], w[1], re, im);
 }

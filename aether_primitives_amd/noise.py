@@ -39,7 +39,12 @@ class Awgn:
 
 
 def philox4x32_10(ctx, counters, keys):
-    """The generator's integer stage on the device: counters (n, 4) and keys (n, 2) uint32 -> (n, 4) uint32."""
+    return philox4x32(ctx, counters, keys, 10)
+
+
+def philox4x32(ctx, counters, keys, rounds=7):
+    """The generator's integer stage on the device (7 rounds; 10 for the other published known answers): counters
+    (n, 4) and keys (n, 2) uint32 -> (n, 4) uint32."""
     import ctypes as C
     c = np.ascontiguousarray(counters, np.uint32).reshape(-1, 4); k = np.ascontiguousarray(keys, np.uint32).reshape(-1, 2)
     n = c.shape[0]
@@ -49,7 +54,7 @@ def philox4x32_10(ctx, counters, keys):
     check(lib.aeth_dev_alloc(ctx.h, ck.nbytes, C.byref(din))); check(lib.aeth_dev_alloc(ctx.h, 16 * n, C.byref(dout)))
     try:
         check(lib.aeth_upload(ctx.h, din, ck.ctypes.data_as(C.c_void_p), ck.nbytes))
-        check(lib.aeth_rng_philox4x32_10(ctx.h, din, n, dout))
+        check(lib.aeth_rng_philox4x32(ctx.h, din, n, rounds, dout))
         out = np.empty((n, 4), np.uint32)
         check(lib.aeth_download(ctx.h, out.ctypes.data_as(C.c_void_p), dout, out.nbytes))
     finally:

@@ -217,6 +217,12 @@ def side_workload(args):
     ctx = ap.Context(ranks.local_rank)
     N = 2048
     scaling = "strong"
+    # --as-rank R --of W (one GPU): run rank R's share of a W-rank job and report the throughput W such GPUs would
+    # give together -- a MODEL of the strong-scaling curve (no communication exists to model; labelled in the line)
+    modelled = args.as_rank is not None
+    if modelled:
+        assert args.gpus == 1 and args.of >= 1 and 0 <= args.as_rank < args.of, "--as-rank R --of W needs --gpus 1 and R < W"
+    p_rank, p_world = (args.as_rank, args.of) if modelled else (ranks.rank, args.gpus)
     if args.workload == "c2":
         scaling = "weak"
         n = 1 << 20                                             # 512 frames: 8 MiB, cache-resident by definition
@@ -229,7 +235,7 @@ def side_workload(args):
         shard = "one stream per rank"
     elif args.workload == "c5":
         total_frames, nb = 512, 9
-        lo, frames = frame_shard(total_frames, ranks.rank, args.gpus)
+        lo, frames = frame_shard(total_frames, p_rank, p_world)
         n = 65536 * frames
         f = ap.HipFft(ctx, 65536, max_batch=max(frames, 1))
         nbuf = 2 if frames > 128 else 3
@@ -244,35 +250,59 @@ def side_workload(args):
         name = "C5: 512 x 65536-point FFT (Scale::SN) + 10x linear interpolation, frame-sharded" + (
             " (two calls)" if args.c5_unfused else " (aeth_fft_exec_interpolate)")
         bytes_ = 104 * n
-        shard = f"frame_shard: rank 0 owns frames [{lo}, {lo + frames}) of {total_frames}"
+        shard = f"frame_shard: rank {p_rank} of {p_world} owns frames [{lo}, {lo + frames}) of {total_frames}"
     else:
+        # Work units = (channel, frame range): this rank's channels, each cut into as many frame ranges as it takes to
+        # have at least two units (frames are independent: the noise stream is addressed by position, so a cut channel
+        # decides the same bits).  The units are dealt alternately to TWO contexts = two HIP queues of this GPU, each
+        # running its units' two fused calls in order: the VALU-bound generator of one unit runs beside the
+        # memory-bound correlator of another (tools/c4_lab.py, profiles/r04_c4_lab.json: 144 -> 163 GS/s on one GPU).
         n_channels, frames = 8, 4096
-        mine = channel_of(ranks.rank, args.gpus, n_channels)
-        n = N * frames
-        q = modulation.qpsk(ctx)
-        f = ap.HipFft(ctx, N, max_batch=frames)
+        mine = channel_of(p_rank, p_world, n_channels)
+        cuts = 1 if len(mine) >= 2 or args.c4_one_queue else 2
+        nq = 1 if args.c4_one_queue else 2
+        ctxs = [ctx] + [ap.Context(ranks.local_rank) for _ in range(nq - 1)]
         ref = np.zeros(N, np.complex64); ref[:4] = np.conj(np.array([-1 + 1j, 0, 1 - 1j, 1 - 1j], np.complex64))
-        sig = ctx.vec(ref)
-        chans = []
-        for c in mine:                                          # channel c: its own bits and noise seed (815 + c)
-            rng = np.random.default_rng(815 + c)
-            chans.append((modulation.DeviceBits(ctx, 2 * n, rng.integers(0, 2, 2 * n, dtype=np.uint8)),
-                          noise.new(ctx, 0.01, 815 + c), ctx.empty(n), modulation.DeviceBits(ctx, 2 * n)))
+        per = [dict(ctx=c, q=modulation.qpsk(c), f=ap.HipFft(c, N, max_batch=frames // cuts), sig=c.vec(ref), units=[]) for c in ctxs]
+        k = 0
+        for ch in mine:                                         # channel ch: its own bits and noise seed (815 + ch)
+            rng = np.random.default_rng(815 + ch)
+            allbits = rng.integers(0, 2, 2 * N * frames, dtype=np.uint8)
+            for cut in range(cuts):
+                fr = frames // cuts
+                n_u = N * fr
+                h = per[k % nq]; k += 1
+                awgn = noise.new(h["ctx"], 0.01, 815 + ch)
+                h["units"].append(dict(bits=modulation.DeviceBits(h["ctx"], 2 * n_u, allbits[2 * n_u * cut: 2 * n_u * (cut + 1)]),
+                                       awgn=awgn, pos=n_u * cut, tx=h["ctx"].empty(n_u), rx=modulation.DeviceBits(h["ctx"], 2 * n_u)))
+        n = N * frames
+        rounds = max(len(h["units"]) for h in per)
         if args.c4_unfused:
-            def step(i):                                        # four launches per channel: 52 B of traffic per sample
-                for bits, awgn, txb, rxb in chans:
-                    tx = q.modulate(bits, out=txb); awgn.apply(tx); f.mul_chain(tx, sig); q.demod_naive(tx, out=rxb)
+            def step(i):                                        # four launches per unit: 52 B of traffic per sample
+                for r in range(rounds):
+                    for h in per:
+                        if r < len(h["units"]):
+                            u = h["units"][r]; u["awgn"].offset = u["pos"]
+                            tx = h["q"].modulate(u["bits"], out=u["tx"]); u["awgn"].apply(tx); h["f"].mul_chain(tx, h["sig"]); h["q"].demod_naive(tx, out=u["rx"])
         else:
             def step(i):                                        # two launches: modulate+AWGN, correlate+demod: 20 B per sample
-                for bits, awgn, txb, rxb in chans:
-                    tx = q.modulate_awgn(bits, awgn, out=txb); q.correlate_demod(f, tx, sig, out=rxb)
+                for r in range(rounds):
+                    for h in per:
+                        if r < len(h["units"]):
+                            u = h["units"][r]; u["awgn"].offset = u["pos"]
+                            tx = h["q"].modulate_awgn(u["bits"], u["awgn"], out=u["tx"]); h["q"].correlate_demod(h["f"], tx, h["sig"], out=u["rx"])
+
+        class _All:                                             # what the harness syncs: every queue of this rank
+            def sync(self_):
+                for c in ctxs: c.sync()
+        ctx = _All()
         job_samples = n * n_channels
         name = "C4: 8 channels x (QPSK mod -> AWGN -> FFT-2048 correlate -> hard demod), 4096 frames each" + (
-            " (four calls)" if args.c4_unfused else " (modulate_awgn + mul_ifft_demod)")
+            " (four calls)" if args.c4_unfused else " (modulate_awgn + mul_ifft_demod)") + f", {nq} queue(s) per GPU"
         # unfused: modulate 8 W + awgn 8 R + 8 W + correlate 8 R + 8 W + demod 8 R (+ 2 x 2 B of bits) = 52 B/sample;
         # fused: modulate_awgn 2 R + 8 W, correlate + demod 8 R + 2 W = 20 B/sample
         bytes_ = (52 if args.c4_unfused else 20) * n * len(mine)
-        shard = f"channel_of: rank 0 runs channels {mine}"
+        shard = f"channel_of: rank {p_rank} of {p_world} runs channels {mine}" + (f", each cut into {cuts} frame ranges" if cuts > 1 else "")
     ranks.barrier(ctx)
     seen = ranks.ranks_seen()
     nsettle = settle(step, ctx, args.settle_ms)
@@ -282,7 +312,9 @@ def side_workload(args):
     ctx.sync(); el = ranks.max_over_ranks(time.perf_counter() - t0)
     if ranks.rank == 0:
         assert seen == args.gpus, f"collective spans {seen} ranks, --gpus says {args.gpus}"
-        print(json.dumps({"metric": "GSamples/s cf32", "value": round(job_samples * args.steps / el / 1e9, 3),
+        extra = {"modelled": f"one GPU ran rank {p_rank}'s share of a {p_world}-GPU job; value = the job's samples / this rank's time "
+                             f"(the ranks share nothing, so the job ends when its slowest rank does)", "as_rank": p_rank, "of": p_world} if modelled else {}
+        print(json.dumps({"metric": "GSamples/s cf32", "value": round(job_samples * args.steps / el / 1e9, 3), **extra,
                           "unit": "GSamples/s", "n_gpus": seen, "steps": args.steps, "warmup": args.warmup,
                           "settle_launches": nsettle, "ms_per_step": round(el / args.steps * 1e3, 5),
                           "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
@@ -319,6 +351,9 @@ def main():
                           "the previous one to drain; this is also the mode to profile per-kernel durations in")
     ap_.add_argument("--no-single-queue-leg", action="store_true",
                      help="skip the extra leg that repeats the timed steps on one queue (per-launch kernel time)")
+    ap_.add_argument("--as-rank", type=int, default=None, help="--workload c4|c5 on ONE GPU: run this rank's share of an --of W rank job (modelled scaling)")
+    ap_.add_argument("--of", type=int, default=1)
+    ap_.add_argument("--c4-one-queue", action="store_true", help="--workload c4 on one context / one HIP queue per GPU (round 3's layout)")
     ap_.add_argument("--c4-unfused", action="store_true", help="--workload c4 as four calls per channel (modulate, apply, mul_chain, demod)")
     ap_.add_argument("--c5-unfused", action="store_true", help="--workload c5 as two calls (fft, then interpolate)")
     ap_.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],

@@ -401,7 +401,7 @@ AETH_API int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym_dev, size_t ns
 /* Awgn::apply (:53-59) on a device-resident signal: s[i] += next().scale(scale) with
  * scale = sqrt(power) (:35) and next() = (z.re * scale, z.im * scale) (:39-43) -- the
  * reference scales twice, so the noise amplitude is proportional to `power`; reproduced.
- * z comes from the library's own counter-based generator (Philox4x32-10 + Box-Muller,
+ * z comes from the library's own counter-based generator (Philox4x32-7 + Box-Muller,
  * position `offset + i` of stream `seed`; DEFAULT seed of the reference is 815, :6): the
  * reference's StdRng stream is not reproducible, results agree bit for bit with the CPU
  * restatement of THIS generator only.  Consecutive calls continue a stream by passing
@@ -414,8 +414,10 @@ AETH_API int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal_dev, size_t n, flo
 AETH_API int aeth_awgn_fill(aeth_ctx *ctx, aeth_cf32 *target_dev, size_t n, float power, uint64_t seed,
                             uint64_t offset);
 /* The generator's integer stage by itself (replaces rand::StdRng, src/noise.rs:2-4,23,33): out[i][0..3] =
- * Philox4x32-10 of counter ctr_key[i][0..3] under key ctr_key[i][4..5] (Salmon et al., SC'11; the Random123
- * known-answer vectors are in tests/golden/philox4x32_10_kat.json).  Device pointers, n x 6 and n x 4 words. */
+ * Philox4x32-R of counter ctr_key[i][0..3] under key ctr_key[i][4..5] (Salmon et al., SC'11), R = 7 (what the
+ * generator draws with since round 4: the smallest Crush-resistant round count of this width) or 10; the Random123
+ * known-answer vectors of both are in tests/golden/philox4x32_{7,10}_kat.json.  Device pointers, n x 6 and n x 4 words. */
+AETH_API int aeth_rng_philox4x32(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, int rounds, uint32_t *out_dev);
 AETH_API int aeth_rng_philox4x32_10(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, uint32_t *out_dev);
 
 #ifdef __cplusplus

@@ -329,9 +329,63 @@ public:
         check(aeth_fir_exec_decim(h_, hist ? hist->ptr() : nullptr, x.ptr(), x.len(), y.ptr(), y.len()));
     }
 
+    aeth_fir *get() const { return h_; }
+
 private:
     aeth_fir *h_ = nullptr;
 };
+
+// ---- pipeline (src/pipeline.rs:24-41 add_stage, :123-137 new, :89-114 the per-stage report) ------------------
+// The reference chains closures over channels; the device pipeline has five fixed stages (copy-in | upload | compute |
+// download | copy-out) and the compute stage is one of the library's ops:
+//     auto y = pipeline::stage_fft(fft, Scale::SN()).run(ctx, x);            // Vec<cf32> -> Vec<cf32>
+//     auto b = pipeline::stage_correlate_demod(fft, sig, 2).run_bits(ctx, x);  // Vec<cf32> -> Vec<u8>
+namespace pipeline {
+struct Stage {
+    aeth_stream_op op{};
+    size_t out_count(Context &ctx, size_t n_in) const { return aeth_stream_out_count(ctx.get(), &op, n_in); }
+    // host slices; with report = true the reference's per-stage lines go to stdout
+    aeth_pipe_util run(Context &ctx, const void *in, size_t n_in, void *out, size_t n_out, size_t chunk = 0, bool report = false) const
+    {
+        aeth_pipe_util u{};
+        check(aeth_stream_host_util(ctx.get(), &op, in, n_in, out, n_out, chunk, &u));
+        if (report) Fir::print_report(u);
+        return u;
+    }
+    std::vector<cf32> run(Context &ctx, const std::vector<cf32> &x, size_t chunk = 0) const
+    {
+        std::vector<cf32> y(out_count(ctx, x.size()));
+        run(ctx, x.data(), x.size(), y.data(), y.size(), chunk);
+        return y;
+    }
+    std::vector<uint8_t> run_bits(Context &ctx, const std::vector<cf32> &x, size_t chunk = 0) const
+    {
+        std::vector<uint8_t> y(out_count(ctx, x.size()));
+        run(ctx, x.data(), x.size(), y.data(), y.size(), chunk);
+        return y;
+    }
+};
+inline Stage stage_fir(const Fir &f) { Stage s; s.op.kind = AETH_STREAM_FIR; s.op.fir = f.get(); return s; }
+inline Stage stage_fft(const HipFft &f, Scale sc, int sign = HipFft::kFwdSign)
+{
+    Stage s; s.op.kind = AETH_STREAM_FFT; s.op.fft = f.get(); s.op.sign = sign; s.op.scale_kind_fwd = sc.kind; s.op.x_fwd = sc.x; return s;
+}
+inline Stage stage_mul_chain(const HipFft &f, const DeviceVec &sig, Scale s_fwd, Scale s_bwd)
+{
+    Stage s; s.op.kind = AETH_STREAM_FFT_MUL_IFFT; s.op.fft = f.get(); s.op.sig_dev = sig.ptr(); s.op.n_sig = sig.len();
+    s.op.scale_kind_fwd = s_fwd.kind; s.op.x_fwd = s_fwd.x; s.op.scale_kind_bwd = s_bwd.kind; s.op.x_bwd = s_bwd.x; return s;
+}
+inline Stage stage_correlate_demod(const HipFft &f, const DeviceVec &sig, int bits_per_symbol, bool compat = true)
+{
+    Stage s; s.op.kind = AETH_STREAM_FFT_MUL_IFFT_DEMOD; s.op.fft = f.get(); s.op.sig_dev = sig.ptr(); s.op.n_sig = sig.len();
+    s.op.bits_per_symbol = bits_per_symbol; s.op.compat = compat ? 1 : 0; return s;
+}
+inline Stage stage_fft_interpolate(const HipFft &f, size_t n_between, Scale sc, bool compat_im = true)
+{
+    Stage s; s.op.kind = AETH_STREAM_FFT_INTERPOLATE; s.op.fft = f.get(); s.op.sign = HipFft::kFwdSign; s.op.scale_kind_fwd = sc.kind;
+    s.op.x_fwd = sc.x; s.op.n_between = n_between; s.op.compat = compat_im ? 1 : 0; return s;
+}
+}  // namespace pipeline
 
 // ---- sampling (src/sampling.rs) ---------------------------------------------------------
 // appends to dst, as the reference does (sampling.rs:17,23)

@@ -587,10 +587,12 @@ int orc_demod_naive(const orc_cf32 *sym, size_t nsym, int bps, const orc_cf32 *t
 
 void orc_rng_cnormal(uint64_t seed, uint64_t idx, float *re, float *im) { aeth_rng_cnormal(seed, idx, re, im); }
 
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4])
 {
-    aeth_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+    aeth_philox4x32(rounds, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32(ctr, key, 10, out); }
 
 /* Awgn::fill (noise.rs:61-65): push next() until the capacity is reached; next() scales once (noise.rs:39-43) */
 void orc_awgn_fill(orc_cf32 *target, size_t n, float power, uint64_t seed, uint64_t offset)

@@ -111,6 +111,7 @@ def lib():
             "orc_awgn_apply": (None, [vp, sz, f32, C.c_uint64, C.c_uint64]),
             "orc_awgn_fill": (None, [vp, sz, f32, C.c_uint64, C.c_uint64]),
             "orc_philox4x32_10": (None, [vp, vp, vp]),
+            "orc_philox4x32": (None, [vp, vp, i32, vp]),
             "orc_synth_cnormal": (None, [C.c_uint64, vp, sz]),
             "orc_synth_lowpass_taps": (None, [sz, f64, vp]),
         }
@@ -340,6 +341,11 @@ def awgn_fill(n, power, seed=815, offset=0):
 def philox4x32_10(counter, key):
     c = np.ascontiguousarray(counter, np.uint32); k = np.ascontiguousarray(key, np.uint32); o = np.empty(4, np.uint32)
     lib().orc_philox4x32_10(c.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p)); return o
+
+
+def philox4x32(counter, key, rounds):
+    c = np.ascontiguousarray(counter, np.uint32); k = np.ascontiguousarray(key, np.uint32); o = np.empty(4, np.uint32)
+    lib().orc_philox4x32(c.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p), int(rounds), o.ctypes.data_as(C.c_void_p)); return o
 
 
 def awgn_apply(signal, power, seed=815, offset=0):

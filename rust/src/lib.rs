@@ -204,6 +204,49 @@ impl<'c> Fir<'c> {
 }
 impl<'c> Drop for Fir<'c> { fn drop(&mut self) { unsafe { aeth_fir_destroy(self.h); } } }
 
+/// The device counterpart of `pipeline::new().add_stage(..)` (src/pipeline.rs:24-41, :123-137): five fixed stages --
+/// copy-in | upload | compute | download | copy-out -- whose compute stage is one of the library's device ops (a closure
+/// cannot cross the C ABI).  `run` takes host slices and returns what `aeth_stream_host` reports.
+pub struct Stage<'c> { op: aeth_stream_op, ctx: &'c Context }
+impl<'c> Stage<'c> {
+    fn blank(ctx: &'c Context, kind: std::os::raw::c_int) -> Stage<'c> {
+        Stage { ctx, op: aeth_stream_op { kind, fir: ptr::null_mut(), fft: ptr::null_mut(), sig_dev: ptr::null(), n_sig: 0, sign: 0,
+                                          scale_kind_fwd: 0, x_fwd: 0.0, scale_kind_bwd: 0, x_bwd: 0.0, bits_per_symbol: 0,
+                                          table_host: ptr::null(), compat: 0, n_between: 0 } }
+    }
+    pub fn fir(ctx: &'c Context, f: &Fir<'c>) -> Stage<'c> { let mut s = Stage::blank(ctx, AETH_STREAM_FIR); s.op.fir = f.h; s }
+    /// `Fft::fwd` over `chunks_mut(fft_len)` (src/util/plot.rs:59-61)
+    pub fn fft(ctx: &'c Context, f: &HipFft<'c>, scale: Scale) -> Stage<'c> {
+        let (k, x) = scale_args(scale);
+        let mut s = Stage::blank(ctx, AETH_STREAM_FFT); s.op.fft = f.h; s.op.sign = AETH_SIGN_REF_FWD; s.op.scale_kind_fwd = k; s.op.x_fwd = x; s
+    }
+    /// `vec_rfft -> vec_mul(&sig) -> vec_rifft` per frame (benches/benches.rs:410-416)
+    pub fn mul_chain(ctx: &'c Context, f: &HipFft<'c>, sig: &DeviceVec, s_fwd: Scale, s_bwd: Scale) -> Stage<'c> {
+        let (kf, xf) = scale_args(s_fwd); let (kb, xb) = scale_args(s_bwd);
+        let mut s = Stage::blank(ctx, AETH_STREAM_FFT_MUL_IFFT); s.op.fft = f.h; s.op.sig_dev = sig.p; s.op.n_sig = sig.n;
+        s.op.scale_kind_fwd = kf; s.op.x_fwd = xf; s.op.scale_kind_bwd = kb; s.op.x_bwd = xb; s
+    }
+    /// the chain, then `Modulation::demod_naive` (examples/modem.rs:28-31): `bits_per_symbol` bytes out per sample
+    pub fn correlate_demod(ctx: &'c Context, f: &HipFft<'c>, sig: &DeviceVec, bits_per_symbol: usize) -> Stage<'c> {
+        let mut s = Stage::blank(ctx, AETH_STREAM_FFT_MUL_IFFT_DEMOD); s.op.fft = f.h; s.op.sig_dev = sig.p; s.op.n_sig = sig.n;
+        s.op.bits_per_symbol = bits_per_symbol as std::os::raw::c_int; s.op.compat = 1; s
+    }
+    /// the transform, then `sampling::interpolate` per frame (src/sampling.rs:7-24)
+    pub fn fft_interpolate(ctx: &'c Context, f: &HipFft<'c>, n_between: usize, scale: Scale) -> Stage<'c> {
+        let (k, x) = scale_args(scale);
+        let mut s = Stage::blank(ctx, AETH_STREAM_FFT_INTERPOLATE); s.op.fft = f.h; s.op.sign = AETH_SIGN_REF_FWD;
+        s.op.scale_kind_fwd = k; s.op.x_fwd = x; s.op.n_between = n_between; s.op.compat = 1; s
+    }
+    pub fn out_count(&self, n_in: usize) -> usize { unsafe { aeth_stream_out_count(self.ctx.h, &self.op, n_in) } }
+    /// cf32 in, `T` out (`cf32`, or `u8` for the demodulating stage); `out.len()` must be `out_count(x.len())`
+    pub fn run<T: Copy>(&self, x: &[cf32], out: &mut [T]) -> aeth_pipe_stats {
+        assert_eq!(out.len(), self.out_count(x.len()), "Vectors must have same length");
+        let mut st = aeth_pipe_stats::default();
+        check(unsafe { aeth_stream_host(self.ctx.h, &self.op, x.as_ptr() as *const _, x.len(), out.as_mut_ptr() as *mut _, out.len(), 0, &mut st) });
+        st
+    }
+}
+
 /// Pinned host buffers behind the reference's `pool::Pool<T>` (src/pool.rs:43-221): `take`, `take_or_make`, `len`,
 /// `cap`; an `Elem` derefs into `[cf32]` and goes back to the pool on drop.  Elements are page-locked once by the
 /// library, so `Fir::filter_stream` copies from / to them directly (no staging, no registration of caller memory).

@@ -194,6 +194,50 @@ int main()
         DeviceVec x(ctx, 7000), y(ctx, 2333); fir.filter_decim(x, y);
     });
 
+    // src/pipeline.rs:24-41,123-137 -- a pipeline whose compute stage is one of the device ops: host slices in, host
+    // slices out, bit-identical to the device flavour on the whole slice
+    RUN("pipeline: fft frames, correlator chain, correlate + demod, fft + interpolate", {
+        const size_t N = 1024, frames = 96, n = N * frames;
+        std::vector<cf32> x(n), sigh(N);
+        for (size_t i = 0; i < n; i++) x[i] = cf32(std::sin(0.37f * i), std::cos(0.11f * i));
+        for (size_t i = 0; i < N; i++) sigh[i] = cf32(1.0f / (1 + i % 7), 0.25f * (i % 3));
+        HipFft fft(ctx, N, frames);
+        DeviceVec sig(ctx, sigh);
+        {   // FFT frames
+            DeviceVec d(ctx, x); fft.ifwd(d, Scale::SN());
+            const std::vector<cf32> y = pipeline::stage_fft(fft, Scale::SN()).run(ctx, x, N * 10);
+            if (y.size() != n || std::memcmp(y.data(), d.to_host().data(), n * sizeof(cf32)) != 0) throw Panic(0, "fft stream != device flavour");
+        }
+        {   // vec_rfft -> vec_mul -> vec_rifft per frame (benches.rs:410-416)
+            DeviceVec d(ctx, x); fft.mul_chain(d, sig, Scale::None(), Scale::N());
+            const std::vector<cf32> y = pipeline::stage_mul_chain(fft, sig, Scale::None(), Scale::N()).run(ctx, x, N * 7);
+            if (std::memcmp(y.data(), d.to_host().data(), n * sizeof(cf32)) != 0) throw Panic(0, "chain stream != device flavour");
+        }
+        {   // ... then demod_naive: 8 B in, 2 bytes out per sample
+            const pipeline::Stage st = pipeline::stage_correlate_demod(fft, sig, 2);
+            if (st.out_count(ctx, n) != 2 * n) throw Panic(0, "out_count");
+            const std::vector<uint8_t> b = st.run_bits(ctx, x, N * 16);
+            std::vector<uint8_t> want(2 * n);
+            void *dbits = nullptr; check(aeth_dev_alloc(ctx.get(), 2 * n, &dbits));
+            DeviceVec d(ctx, x);
+            check(aeth_fft_mul_ifft_demod(fft.get(), d.ptr(), n, frames, sig.ptr(), N, 0, 0.f, 0, 0.f, 2, nullptr, (uint8_t *)dbits, 2 * n, 1));
+            check(aeth_download(ctx.get(), want.data(), dbits, 2 * n)); check(aeth_dev_free(ctx.get(), dbits));
+            if (b != want) throw Panic(0, "demod stream != device flavour");
+        }
+        {   // the transform, then sampling::interpolate per frame: 1 in, n_between + 1 out
+            const size_t nb = 4, out_n = (N + (N - 1) * nb) * frames;
+            const pipeline::Stage st = pipeline::stage_fft_interpolate(fft, nb, Scale::SN());
+            if (st.out_count(ctx, n) != out_n) throw Panic(0, "out_count");
+            const std::vector<cf32> y = st.run(ctx, x, N * 9);
+            DeviceVec d(ctx, x), o(ctx, out_n); size_t wrote = 0;
+            check(aeth_fft_exec_interpolate(fft.get(), d.ptr(), n, frames, HipFft::kFwdSign, AETH_SCALE_SN, 0.f, o.ptr(), out_n, nb, 1, &wrote));
+            if (wrote != out_n || std::memcmp(y.data(), o.to_host().data(), out_n * sizeof(cf32)) != 0) throw Panic(0, "interpolate stream != device flavour");
+        }
+        EXPECT_PANIC("pipeline: ragged input", "Input and FFT must be the same length",
+                     { std::vector<cf32> r(N + 1), o(N + 1); pipeline::stage_fft(fft, Scale::None()).run(ctx, r.data(), r.size(), o.data(), o.size()); });
+        check(aeth_ctx_trim(ctx.get()));
+    });
+
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "PASSED", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
 }

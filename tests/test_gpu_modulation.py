@@ -143,22 +143,27 @@ def test_generic_tables_follow_the_trait_defaults(ctx, oracle, bps):
         mod.modulate(np.zeros(bps + 1, np.uint8))
 
 
-def test_philox_known_answers_on_the_device(ctx, oracle):
-    """The generator's integer stage as the GPU runs it, against the Random123 known-answer vectors (fixture) and,
-    on random counters/keys, against the oracle's independent restatement."""
+@pytest.mark.parametrize("rounds", [7, 10])
+def test_philox_known_answers_on_the_device(ctx, oracle, rounds):
+    """The generator's integer stage as the GPU runs it (seven rounds; ten, the other published set, too), against the
+    Random123 known-answer vectors (fixtures) and, on random counters/keys, against the oracle's independent restatement."""
     import json, os
-    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "philox4x32_10_kat.json")))["cases"]
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"philox4x32_{rounds}_kat.json")))["cases"]
     ctr = np.array([[int(x, 16) for x in c["counter"]] for c in kat], np.uint32)
     key = np.array([[int(x, 16) for x in c["key"]] for c in kat], np.uint32)
-    got = noise.philox4x32_10(ctx, ctr, key)
+    got = noise.philox4x32(ctx, ctr, key, rounds)
     for g, c in zip(got, kat):
         assert [f"{v:08x}" for v in g] == c["expected"], c["name"]
     rng = np.random.default_rng(5)
     ctr = rng.integers(0, 2 ** 32, (5000, 4), dtype=np.uint64).astype(np.uint32)
     key = rng.integers(0, 2 ** 32, (5000, 2), dtype=np.uint64).astype(np.uint32)
-    got = noise.philox4x32_10(ctx, ctr, key)
+    got = noise.philox4x32(ctx, ctr, key, rounds)
     for i in range(0, 5000, 37):
-        assert (got[i] == oracle.philox4x32_10(ctr[i], key[i])).all()
+        assert (got[i] == oracle.philox4x32(ctr[i], key[i], rounds)).all()
+    if rounds == 10:
+        assert (noise.philox4x32_10(ctx, ctr[:8], key[:8]) == got[:8]).all()
+    with pytest.raises(ap.AetherError):
+        noise.philox4x32(ctx, ctr[:1], key[:1], 8)
 
 
 @pytest.mark.parametrize("n,offset", [(1, 0), (2, 1), (7, 0), (4097, 3), (1 << 20, 1 << 33)])

@@ -245,15 +245,31 @@ def test_synth_is_deterministic(oracle):
     assert 0.9 < p < 1.1
 
 
-def test_philox4x32_10_known_answers(oracle):
-    """The oracle's Philox4x32-10 (the integer stage of the AWGN generator) against the Random123 distribution's
-    own known-answer vectors: zero, all-ones and pi-digits counter/key sets."""
+@pytest.mark.parametrize("rounds", [7, 10])
+def test_philox4x32_known_answers(oracle, rounds):
+    """The oracle's Philox4x32-R (the integer stage of the AWGN generator: seven rounds since round 4, ten before)
+    against the Random123 distribution's own known-answer vectors: zero, all-ones and pi-digits counter/key sets."""
     import json, os
-    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "philox4x32_10_kat.json")))
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"philox4x32_{rounds}_kat.json")))
     assert len(kat["cases"]) >= 3
     for c in kat["cases"]:
-        got = oracle.philox4x32_10([int(x, 16) for x in c["counter"]], [int(x, 16) for x in c["key"]])
+        got = oracle.philox4x32([int(x, 16) for x in c["counter"]], [int(x, 16) for x in c["key"]], rounds)
         assert [f"{v:08x}" for v in got] == c["expected"], c["name"]
+        if rounds == 10:
+            assert (oracle.philox4x32_10([int(x, 16) for x in c["counter"]], [int(x, 16) for x in c["key"]]) == got).all()
+
+
+def test_generator_log_is_a_logarithm(oracle):
+    """the division-free ln of the Box-Muller stage (Cephes' logf polynomial): radius^2 = -2 ln u for the whole range of
+    u the generator can draw, against float64 -- and the extreme draws stay finite (u = 1 gives radius 0, u = 2^-24 the
+    largest radius, 5.77)"""
+    import numpy as np
+    n = 1 << 16
+    z = oracle.awgn_fill(n, 1.0, seed=3)
+    assert np.isfinite(z.view(np.float32)).all()
+    # sample k of the stream is sqrt(-2 ln u) (cos, sin): |z|^2 must follow the chi-square(2) law the definition implies
+    r2 = np.abs(z.astype(np.complex128)) ** 2
+    assert abs(r2.mean() - 2.0) < 0.05 and r2.max() < 2 * 24 * np.log(2) + 1e-3
 
 
 def test_awgn_fill_scales_once_apply_twice(oracle):
