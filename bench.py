@@ -323,6 +323,105 @@ def side_workload(args):
     ranks.close()
 
 
+def criterion_shapes(args):
+    """The reference's criterion shapes (benches/benches.rs:30-67 vec ops @ 2048, :92 interpolate, :113,130 downsample,
+    :310-377 FFT 512/1024/2048, :410-420 correlator, :223,260 mod/demod), ONE frame per call as the reference runs
+    them: the oracle's CPU time (this leg is bench.py's CPU-baseline use of oracle/), the literal host flavour (host
+    slice in, H2D -> kernel -> D2H, host slice out: the drop-in trait call) and the device flavour (operands resident,
+    one launch; `sync` = call + wait, `pipelined` = 200 calls back to back / 200).  Then, for FFT-2048 and the
+    correlator chain, the batch size from which each flavour beats `batch` CPU calls."""
+    import ctypes as C
+    import aether_primitives_amd as ap
+    from aether_primitives_amd import Scale, sampling, modulation
+    from oracle import pyoracle
+    ctx = ap.Context(0)
+    lib = ctx._lib
+    L, flags = pyoracle.native_fir_lib()
+    if L is not None:
+        L.orc_time_shape.restype = C.c_double; L.orc_time_shape.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_int]
+        cpu = lambda op, n, b=0: min(L.orc_time_shape(op, n, b, 2000) for _ in range(3)) * 1e6
+    else:
+        flags = "portable -O2 build"
+        cpu = lambda op, n, b=0: min(pyoracle.time_shape(op, n, b, 2000) for _ in range(3)) * 1e6
+
+    def t_sync(fn, reps=200):
+        for _ in range(10): fn()
+        ctx.sync(); best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps): fn(); ctx.sync()
+            best = min(best, (time.perf_counter() - t0) / reps)
+        return best * 1e6
+
+    def t_pipe(fn, reps=200):
+        for _ in range(10): fn()
+        ctx.sync(); best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps): fn()
+            ctx.sync(); best = min(best, (time.perf_counter() - t0) / reps)
+        return best * 1e6
+
+    rows = []
+    def row(name, ref, cpu_us, host_fn, dev_fn):
+        r = {"shape": name, "reference": ref, "cpu_us": round(cpu_us, 3), "host_flavour_us": round(t_sync(host_fn, 100), 2),
+             "device_sync_us": round(t_sync(dev_fn), 2), "device_pipelined_us": round(t_pipe(dev_fn), 2)}
+        rows.append(r); print(r, flush=True)
+
+    ones = lambda n: np.full(n, 1 + 1j, np.complex64)
+    # vec ops @ 2048 (benches.rs:30-67)
+    a, b = ap.HostVec(ctx, ones(2048)), ap.HostVec(ctx, ones(2048))
+    da, db = ctx.vec(ones(2048)), ctx.vec(ones(2048))
+    row("vec_mul 2048", "benches.rs:37", cpu(0, 2048), lambda: a.vec_mul(b), lambda: da.vec_mul(db))
+    row("vec_scale 2048", "benches.rs:48", cpu(1, 2048), lambda: a.vec_scale(1.0), lambda: da.vec_scale(1.0))
+    row("vec_clone 2048", "benches.rs:59", cpu(2, 2048), lambda: a.vec_clone(b), lambda: da.vec_clone(db))
+    # interpolate (len, n_between): the bench passes n_between = 4 whatever the tuple says (benches.rs:88)
+    for n in (1024, 2048, 400):
+        src = (np.arange(n) + 0j).astype(np.complex64); dsrc = ctx.vec(src); ddst = ctx.empty(n + (n - 1) * 4)
+        hdst = np.empty(n + (n - 1) * 4, np.complex64); nw = C.c_size_t()
+        host = lambda: lib.aeth_host_interpolate(ctx.h, src.ctypes.data_as(C.c_void_p), n, hdst.ctypes.data_as(C.c_void_p), hdst.size, 4, 1, C.byref(nw))
+        row(f"interpolate {n} x5", "benches.rs:76-92", cpu(3, n, 4), host, lambda: sampling.interpolate(ctx, dsrc, ddst, 4))
+    # downsample, release build (benches.rs:99-130)
+    for n, m in ((30720, 1024), (8096, 512)):
+        src = ones(n); dst = np.empty(m, np.complex64); dsrc = ctx.vec(src); ddst = ctx.empty(m)
+        row(f"downsample {n} -> {m}", "benches.rs:113,130", cpu(4, n, m), lambda: sampling.downsample(ctx, src, dst, release=True),
+            lambda: sampling.downsample(ctx, dsrc, ddst, release=True))
+    # FFT in place / copy, Scale::SN (benches.rs:294-377), correlator chain (:388-420)
+    for n in (512, 1024, 2048):
+        f = ap.HipFft(ctx, n); x = ones(n); y = np.empty(n, np.complex64); dx = ctx.vec(x); dy = ctx.empty(n)
+        sigd = ctx.vec(ones(n))
+        row(f"fft ifwd SN {n}", "benches.rs:294-310", cpu(5, n), lambda: f.ifwd(x, Scale.SN), lambda: f.ifwd(dx, Scale.SN))
+        row(f"fft fwd SN copy {n}", "benches.rs:340-357", cpu(6, n), lambda: f.fwd(x, y, Scale.SN), lambda: f.fwd(dx, dy, Scale.SN))
+        hx = ap.HostVec(ctx, x); hs = ap.HostVec(ctx, ones(n))
+        row(f"correlator chain {n}", "benches.rs:388-420", cpu(7, n),
+            lambda: hx.vec_rfft(f, Scale.NONE).vec_mul(hs).vec_rifft(f, Scale.NONE), lambda: f.mul_chain(dx, sigd))
+    # modulation (benches.rs:210-278)
+    q = modulation.qpsk(ctx)
+    for n in (100, 8000):
+        bits = np.random.default_rng(n).integers(0, 2, n - n % 2, dtype=np.uint8); dbits = modulation.DeviceBits(ctx, bits.size, bits)
+        dsym = ctx.empty(bits.size // 2); dout = modulation.DeviceBits(ctx, 2 * n); syms = ctx.vec(ones(n))
+        row(f"qpsk modulate {n} bits", "benches.rs:210-223", cpu(8, n), lambda: q.modulate(bits).to_host(), lambda: q.modulate(dbits, out=dsym))
+        row(f"qpsk demod_naive {n} symbols", "benches.rs:245-260", cpu(9, n), lambda: q.demod_naive(syms, out=dout).to_host(), lambda: q.demod_naive(syms, out=dout))
+    # from which batch does the GPU win?  FFT-2048 ifwd(SN) and the correlator chain on `batch` frames in ONE call
+    cross = []
+    f = ap.HipFft(ctx, 2048, max_batch=4096); sigd = ctx.vec(ones(2048))
+    c_fft, c_chain = cpu(5, 2048), cpu(7, 2048)
+    for batch in (1, 2, 4, 8, 16, 64, 256, 1024, 4096):
+        x = np.tile(ones(2048), batch); dx = ctx.vec(x); hv = np.empty_like(x)
+        def host_fft():                                     # upload, one batched launch, download: what a caller with host data pays
+            ctx.upload(dx.ptr, x); f.ifwd(dx, Scale.SN); ctx.download(dx.ptr, hv)
+        def host_chain():
+            ctx.upload(dx.ptr, x); f.mul_chain(dx, sigd); ctx.download(dx.ptr, hv)
+        r = {"batch": batch, "cpu_fft_us": round(c_fft * batch, 1), "gpu_fft_device_us": round(t_sync(lambda: f.ifwd(dx, Scale.SN), 50), 2),
+             "gpu_fft_host_data_us": round(t_sync(host_fft, 30), 2), "cpu_chain_us": round(c_chain * batch, 1),
+             "gpu_chain_device_us": round(t_sync(lambda: f.mul_chain(dx, sigd), 50), 2), "gpu_chain_host_data_us": round(t_sync(host_chain, 30), 2)}
+        cross.append(r); print(r, flush=True)
+    out = {"cpu": f"oracle/aeth_oracle.c (c++-restatement-of-rust-path), 1 thread, gcc {flags}, {cpu_model()}", "one_frame_per_call": rows,
+           "batched_fft2048": cross}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "criterion_shapes.json"), "w"), indent=1)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD process
     (torch.distributed.run) before this process touches torch or the GPU, and leave with its return code."""
@@ -356,11 +455,13 @@ def main():
     ap_.add_argument("--c4-one-queue", action="store_true", help="--workload c4 on one context / one HIP queue per GPU (round 3's layout)")
     ap_.add_argument("--c4-unfused", action="store_true", help="--workload c4 as four calls per channel (modulate, apply, mul_chain, demod)")
     ap_.add_argument("--c5-unfused", action="store_true", help="--workload c5 as two calls (fft, then interpolate)")
-    ap_.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5"],
+    ap_.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c5", "criterion"],
                      help="c3 (default) = the headline config; the others are BASELINE configs 2, 4, 5 for the record")
     args = ap_.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
+    if args.workload == "criterion":
+        return criterion_shapes(args)
     if args.workload != "c3":
         return side_workload(args)
 

@@ -618,6 +618,57 @@ void orc_awgn_apply(orc_cf32 *signal, size_t n, float power, uint64_t seed, uint
 }
 
 /* ======================================================================= */
+/* timing of the reference's criterion shapes (benches/benches.rs) for bench.py's CPU-baseline leg:     */
+/* seconds per iteration of ONE call of the restated op on the shape, buffers set up outside the clock  */
+/* as criterion's iter_with_setup does.  op: 0 vec_mul(n) :37, 1 vec_scale(n) :48, 2 vec_clone(n) :59,  */
+/* 3 interpolate(n, n_between = b) :76-92, 4 downsample release build (n -> b) :99-113, 5 Cfft ifwd SN  */
+/* (n) :294-310, 6 Cfft fwd SN copy (n) :340-357, 7 correlator chain rfft -> vec_mul -> rifft (n)        */
+/* :388-420, 8 qpsk modulate (n bits) :210-223, 9 qpsk demod_naive (n symbols) :245-260                   */
+/* ======================================================================= */
+#include <time.h>
+static double orc_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+double orc_time_shape(int op, size_t n, size_t b, int reps)
+{
+    if (n == 0 || reps < 1) return -1.0;
+    const size_t big = (op == 3 ? n + (n - 1) * b : n) + 16;
+    orc_cf32 *x = (orc_cf32 *)malloc(big * sizeof(orc_cf32)), *y = (orc_cf32 *)malloc(big * sizeof(orc_cf32));
+    uint8_t *bits = (uint8_t *)malloc(2 * n + 16);
+    if (!x || !y || !bits) { free(x); free(y); free(bits); return -1.0; }
+    for (size_t i = 0; i < big; i++) { x[i].re = 1.0f; x[i].im = 1.0f; y[i].re = 1.0f; y[i].im = 1.0f; }
+    for (size_t i = 0; i < 2 * n; i++) bits[i] = (uint8_t)((i * 2654435761u >> 13) & 1u);
+    orc_fft_plan *plan = (op >= 5 && op <= 7) ? orc_fft_plan_create(n) : NULL;
+    volatile float sink = 0.f;
+    double t0 = orc_now();
+    for (int r = 0; r < reps; r++) {
+        switch (op) {
+        case 0: orc_vec_mul(x, n, y, n); break;
+        case 1: orc_vec_scale(x, n, 1.0f); break;
+        case 2: orc_vec_clone(x, n, y, n); break;
+        case 3: sink += (float)orc_interpolate(x, n, y, b, 1); break;
+        case 4: orc_downsample_release(x, n, y, b, sizeof(orc_cf32), 0); break;
+        case 5: orc_cfft_inplace(plan, x, n, ORC_SIGN_REF_FWD, ORC_SCALE_SN, 0.0f); break;
+        case 6: orc_cfft_outofplace(plan, x, n, y, ORC_SIGN_REF_FWD, ORC_SCALE_SN, 0.0f); break;
+        case 7:
+            orc_cfft_inplace(plan, x, n, ORC_SIGN_REF_FWD, ORC_SCALE_NONE, 0.0f);
+            orc_vec_mul(x, n, y, n);
+            orc_cfft_inplace(plan, x, n, ORC_SIGN_REF_BWD, ORC_SCALE_NONE, 0.0f);
+            if (!(x[0].re < 1e30f && x[0].re > -1e30f)) for (size_t i = 0; i < n; i++) { x[i].re = 1.0f; x[i].im = 1.0f; }   /* keep the data finite */
+            break;
+        case 8: orc_qpsk_modulate(bits, n, y); break;
+        case 9: orc_qpsk_demod_naive(x, n, bits); break;
+        default: break;
+        }
+        sink += x[r % n].re + y[r % n].im;
+    }
+    const double el = orc_now() - t0;
+    (void)sink;
+    if (plan) orc_fft_plan_destroy(plan);
+    free(x); free(y); free(bits);
+    return el / (double)reps;
+}
+
+/* ======================================================================= */
 /* synthetic input                                                          */
 /* ======================================================================= */
 

@@ -141,6 +141,8 @@ void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, ui
 /* ---- deterministic synthetic input (the build's own generator) ---------- */
 /* complex normal, unit power (sigma = 1/sqrt(2) per component), splitmix64 +
  * Box-Muller in f64, rounded to f32.  Seed 815 = noise.rs:6. */
+/* seconds per call of a restated op on one of the reference's criterion shapes (bench.py's CPU-baseline leg) */
+double orc_time_shape(int op, size_t n, size_t b, int reps);
 void orc_synth_cnormal(uint64_t seed, orc_cf32 *out, size_t n);
 /* 64-tap style windowed-sinc low-pass (Hamming, cutoff*fs), unit DC gain */
 void orc_synth_lowpass_taps(size_t ntaps, double cutoff, orc_cf32 *taps);

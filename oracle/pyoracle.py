@@ -112,6 +112,7 @@ def lib():
             "orc_awgn_fill": (None, [vp, sz, f32, C.c_uint64, C.c_uint64]),
             "orc_philox4x32_10": (None, [vp, vp, vp]),
             "orc_philox4x32": (None, [vp, vp, i32, vp]),
+            "orc_time_shape": (f64, [i32, sz, sz, i32]),
             "orc_synth_cnormal": (None, [C.c_uint64, vp, sz]),
             "orc_synth_lowpass_taps": (None, [sz, f64, vp]),
         }
@@ -341,6 +342,11 @@ def awgn_fill(n, power, seed=815, offset=0):
 def philox4x32_10(counter, key):
     c = np.ascontiguousarray(counter, np.uint32); k = np.ascontiguousarray(key, np.uint32); o = np.empty(4, np.uint32)
     lib().orc_philox4x32_10(c.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p)); return o
+
+
+def time_shape(op, n, b=0, reps=1000):
+    """seconds per call of restated op `op` on a criterion shape (see orc_time_shape)"""
+    return lib().orc_time_shape(int(op), int(n), int(b), int(reps))
 
 
 def philox4x32(counter, key, rounds):
