@@ -62,6 +62,8 @@ class Context:
 
     @property
     def stream(self):
+        """hipStream_t of the context for interop.  SIDE EFFECT: handing the stream out parks the overlap lane (every
+        later launch stays on this one stream, `overlap` reads False) until `set_overlap(True)` re-arms it."""
         return self._lib.aeth_ctx_stream(self.h)
 
     # ---- device memory ----

@@ -182,7 +182,8 @@ int aeth_ctx_set_overlap(aeth_ctx *ctx, int enable)
     return AETH_OK;
 }
 
-int aeth_ctx_overlap(const aeth_ctx *ctx) { return ctx && ctx->overlap ? 1 : 0; }
+/* 1 only while the lane is in USE: handing the stream out (aeth_ctx_stream) parks it until it is re-armed */
+int aeth_ctx_overlap(const aeth_ctx *ctx) { return ctx && ctx->overlap && !ctx->stream_shared ? 1 : 0; }
 
 int aeth_ctx_create(int device, aeth_ctx **out) { return ctx_make(device, nullptr, false, out); }
 

@@ -6,6 +6,7 @@ memory as a numpy array (`Deref`, :210-221).  Elements are page-locked ONCE by t
 produced into them cross PCIe with true asynchronous copies in `Fir.filter_stream`, with no staging copy and
 without the library ever registering caller memory."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -16,28 +17,48 @@ ZERO_ON_RETURN = 1
 
 
 class Elem:
-    """guard of one checked-out element (pool.rs:188-221): `.array(dtype)` is its memory, `close()` / `del` returns it"""
+    """guard of one checked-out element (pool.rs:188-221): `.array(dtype)` is its memory, `close()` / `del` returns it.
+
+    A numpy array lent by `.array()` (and every view sliced from it) keeps the element checked out: `close()` -- also
+    the end of a `with` block -- hands the element back only once the last such array is gone, so no array ever
+    aliases whoever takes the element next (Rust's borrow of `Deref::deref`, pool.rs:210-221, ends with the guard; a
+    numpy view cannot be ended from outside, so the guard waits for it instead)."""
 
     def __init__(self, pool, ptr):
         self._pool, self._ptr = pool, ptr
+        self._views = 0            # live buffers lent by array()
+        self._closed = False
 
     @property
     def ptr(self):
         return self._ptr
 
     def array(self, dtype=np.complex64, count=None):
-        """the element's memory as a numpy array (valid until the guard is closed)"""
-        assert self._ptr, "element already returned to its pool"
+        """the element's memory as a numpy array; the element goes back to the pool only after the array has died"""
+        assert self._ptr and not self._closed, "element already returned to its pool"
         dt = np.dtype(dtype)
         n = self._pool.elem_bytes // dt.itemsize if count is None else count
         assert n * dt.itemsize <= self._pool.elem_bytes
         buf = (C.c_char * (n * dt.itemsize)).from_address(self._ptr)
+        self._views += 1
+        weakref.finalize(buf, Elem._view_died, self)          # the finalizer holds the guard (and so the pool) alive
         return np.frombuffer(buf, dtype=dt, count=n)
 
+    @staticmethod
+    def _view_died(elem):
+        elem._views -= 1
+        if elem._closed and elem._views == 0:
+            elem._give_back()
+
+    def _give_back(self):
+        ptr, self._ptr = self._ptr, None
+        if ptr and self._pool._h:
+            check(self._pool._lib.aeth_pool_give_back(self._pool._h, C.c_void_p(ptr)))
+
     def close(self):
-        if self._ptr and self._pool._h:
-            check(self._pool._lib.aeth_pool_give_back(self._pool._h, C.c_void_p(self._ptr)))
-        self._ptr = None
+        self._closed = True
+        if self._views == 0:
+            self._give_back()
 
     def __enter__(self): return self
     def __exit__(self, *a): self.close()
@@ -82,8 +103,10 @@ class Pool:
     __len__ = len
 
     def close(self):
-        """refused (ArgError) while elements are checked out"""
-        if self._h and self.ctx.h:
+        """refused (ArgError) while elements are checked out -- also while numpy arrays lent by `Elem.array()` are alive.
+        The C pool keeps its device by value and may outlive its context, so it is destroyed whatever the context's
+        state (its pinned elements and their entries in the pinned-range registry would leak otherwise)."""
+        if self._h:
             check(self._lib.aeth_pool_destroy(self._h))
         self._h = None
 

@@ -101,7 +101,7 @@ AETH_API int aeth_ctx_sync(aeth_ctx *ctx);
  * start of the next; every other call (and aeth_ctx_sync / aeth_event_record) is ordered behind both queues, so
  * results are those of one in-order stream.  Off by default; refused for contexts on a borrowed stream. */
 AETH_API int aeth_ctx_set_overlap(aeth_ctx *ctx, int enable);
-AETH_API int aeth_ctx_overlap(const aeth_ctx *ctx);   /* 1 if enabled */
+AETH_API int aeth_ctx_overlap(const aeth_ctx *ctx);   /* 1 if enabled AND in use (0 while aeth_ctx_stream has parked it) */
 /* hipStream_t of the context, for interop (torch ExternalStream, the caller's own copies and kernels).  Handing it out
  * parks the overlap lane: every later launch stays on this stream, so work the caller enqueues on it is ordered behind
  * the library's, until the caller re-arms the lane with aeth_ctx_set_overlap(ctx, 1). */

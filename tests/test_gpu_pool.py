@@ -38,8 +38,31 @@ def test_reference_resetting(ctx):
         a = e.array(np.uint8)
         a[:] = np.arange(50, dtype=np.uint8)
         assert a.size == 50 and a.sum() > 0
+        del a                                      # the borrow ends before the guard does (pool.rs:210-221)
     with p.take() as e:
         assert not e.array(np.uint8).any()
+    p.close()
+
+
+def test_a_lent_array_keeps_its_element_checked_out(ctx):
+    """a numpy view of an element must never alias whoever takes the element next, nor outlive the pool's
+    memory: the guard hands the element back only when the last array lent from it has died, and the pool refuses to
+    close until then."""
+    p = pool.Pool(ctx, 64, initial_len=1)
+    e = p.take()
+    a = e.array(np.uint8)
+    tail = a[32:]                                  # a view of the view
+    e.close()                                      # (or the end of a `with` block)
+    assert p.len() == 0 and p.take() is None       # still out: `a` and `tail` are alive
+    del a
+    assert p.len() == 0
+    with pytest.raises(ap.AetherError, match="still checked out"):
+        p.close()
+    tail[:] = 7                                    # still valid memory
+    del tail
+    assert p.len() == 1                            # the last array died: now it is back
+    with pytest.raises(AssertionError):
+        e.array(np.uint8)                          # a closed guard lends nothing
     p.close()
 
 
@@ -94,6 +117,7 @@ def test_stream_from_pool_elements_is_direct_and_bit_identical(ctx, n):
         y[:] = 0
         _, st = f.filter_stream(x, out=y)                      # a staged input takes the output through the host stage too
         assert st["pinned"] == 0 and bits_equal(y, want)
+        del xin, y
     z, st = f.filter_stream(x, report=True)
     assert st["pinned"] == 0 and bits_equal(z, want)
     assert st["active_copy_in"] > 0 and st["active_copy_out"] > 0 and len(st["lines"]) == 5

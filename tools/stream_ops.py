@@ -63,6 +63,7 @@ for name, st, n in ops:
               f"{8 * n / best['seconds'] / 1e9:9.1f} {obytes / best['seconds'] / 1e9:10.1f}   {same}  pinned={int(best['pinned'])}", flush=True)
     _, rep = pipeline.run(st, xbig[:n], out=ypage, report=True)
     for l in rep["lines"]: print("        " + l)
+    x = y = None                      # the arrays lent by the elements keep them checked out
     eout.close(); pout.close()
     ctx.trim()
 ein.close(); pin.close()

@@ -51,4 +51,5 @@ for kind in ("pool", "pageable"):
         print(f"n =   64 Mi  {kind:9s} chunk {chunk >> 20:3d} Mi samples  {st['seconds'] * 1e3:8.2f} ms  {(64 << 20) / st['seconds'] / 1e9:5.2f} GS/s  "
               f"{8 * (64 << 20) / st['seconds'] / 1e9:5.1f} GB/s per direction", flush=True)
         for l in st.get("lines", []): print("      " + l)
+y = None                              # the arrays lent by the elements keep them checked out
 ein.close(); eout.close(); pp.close()
