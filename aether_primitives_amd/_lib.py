@@ -10,6 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaether_hip.so")
+# tools/ only: AETH_LAB_LIB=1 loads the lab build of the SAME sources (`make -C aether_primitives_amd/csrc LAB=1`),
+# which keeps the measured-and-not-kept routes reachable through their AETH_* knobs (csrc/aeth_internal.h, lab_int)
+if os.environ.get("AETH_LAB_LIB") == "1":
+    LIB_PATH = os.path.join(_HERE, "lib", "libaether_hip_lab.so")
 
 OK = 0
 E_LEN, E_ARG, E_ALIGN, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
@@ -94,6 +98,7 @@ PROTOTYPES = {
     "aeth_host_register": (i32, [vp, vp, sz]),
     "aeth_host_unregister": (i32, [vp, vp]),
     "aeth_host_is_pinned": (i32, [vp, sz]),
+    "aeth_vec_chain": (i32, [vp, vp, sz, vp, sz]),
     "aeth_stream_out_count": (sz, [vp, vp, sz]),
     "aeth_stream_host": (i32, [vp, vp, vp, sz, vp, sz, sz, vp]),
     "aeth_stream_host_util": (i32, [vp, vp, vp, sz, vp, sz, sz, vp]),

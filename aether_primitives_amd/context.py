@@ -168,6 +168,12 @@ class DeviceVec:
     def _p(self):
         return C.c_void_p(self.ptr)
 
+    def fused(self):
+        """A chain of the element-wise methods as ONE pass over memory (`aeth_vec_chain`): record the links with the
+        usual names, `run()` (or leaving a `with` block) executes them -- bit-identical to the separate calls:
+            v.fused().vec_add(a).vec_mul(b).vec_conj().run()         # BASELINE config 1: one launch, 32 B per sample"""
+        return _Chain(self)
+
     def _other(self, other):
         if isinstance(other, DeviceVec):
             return other
@@ -233,6 +239,42 @@ class DeviceVec:
 
     def vec_rifft(self, fft, scale):                              # vecops.rs:88, :203-207
         fft.ibwd(self, scale); return self
+
+
+class _VecStep(C.Structure):
+    # struct aeth_vec_step
+    _fields_ = [("op", C.c_int), ("other_dev", C.c_void_p), ("n_other", C.c_size_t), ("scale", C.c_float)]
+
+
+class _Chain:
+    """links recorded for DeviceVec.fused(); AETH_VEC_*: scale 0, mul 1, div 2, conj 3, add 4, sub 5, clone 6, zero 7"""
+
+    def __init__(self, vec):
+        self.vec, self.steps, self._keep = vec, [], []
+
+    def _bin(self, op, other):
+        o = self.vec._other(other)
+        self._keep.append(o)
+        self.steps.append(_VecStep(op, o.ptr, o.n, 0.0)); return self
+
+    def vec_scale(self, s): self.steps.append(_VecStep(0, None, 0, float(np.float32(s)))); return self
+    def vec_mul(self, o): return self._bin(1, o)
+    def vec_div(self, o): return self._bin(2, o)
+    def vec_conj(self): self.steps.append(_VecStep(3, None, 0, 0.0)); return self
+    def vec_add(self, o): return self._bin(4, o)
+    def vec_sub(self, o): return self._bin(5, o)
+    def vec_clone(self, o): return self._bin(6, o)
+    def vec_zero(self): self.steps.append(_VecStep(7, None, 0, 0.0)); return self
+
+    def run(self):
+        arr = (_VecStep * max(len(self.steps), 1))(*self.steps)
+        check(self.vec.ctx._lib.aeth_vec_chain(self.vec.ctx.h, self.vec._p(), self.vec.n, arr, len(self.steps)))
+        self.steps, self._keep = [], []
+        return self.vec
+
+    def __enter__(self): return self
+    def __exit__(self, et, ev, tb):
+        if et is None: self.run()
 
 
 class HostVec:

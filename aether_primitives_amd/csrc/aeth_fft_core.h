@@ -587,6 +587,18 @@ __global__ void build_lane_twiddles(const cf *__restrict__ twN, cf *__restrict__
 // barrier in front of the writes keeps late readers safe.
 // XP (tuning): bit 0: the exchange runs at s_setprio 1, the butterflies at 0; bit 1: no barriers, bit 2: no LDS
 // traffic at all (both diagnosis only, wrong results)
+// XP bit 4 (16): raw `s_barrier` behind an explicit lgkmcnt(0) instead of __syncthreads(): the fence of __syncthreads()
+// drains vmcnt(0) whenever an LDS-DMA (a pending LDS write on the VM counter) is in flight, which would make every
+// exchange wait for the window that is still landing (aeth_fir_kernel.h, V_DMA)
+template <int XP> __device__ __forceinline__ void wg_barrier()
+{
+    if constexpr (XP & 16) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else __syncthreads();
+}
+
 template <class C, int PASS, int S, int PAR, int XP = 0>
 __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], cf *__restrict__ lds, int tid)
 {
@@ -597,7 +609,7 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
     if constexpr (!last && !NOLDS) {
         if constexpr (C::DB) img = lds + (((PAR + PASS) & 1) ? C::LDS_ELEMS : 0);
         else if constexpr (XP & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        else __syncthreads();               // earlier readers of the single image are done
+        else wg_barrier<XP>();              // earlier readers of the single image are done
     }
 #pragma unroll
     for (int b = 0; b < B; b++) {
@@ -623,7 +635,7 @@ __device__ __forceinline__ void run_pass(cf (&w)[C::P], const cf (&tw)[C::TW], c
     if constexpr (!last && !NOLDS) {
         if constexpr (XP & 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (XP & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        else __syncthreads();
+        else wg_barrier<XP>();
 #pragma unroll
         for (int m = 0; m < C::P; m++) w[m] = img[pidx<XP>(tid + m * C::T)];
         if constexpr (XP & 1) __builtin_amdgcn_s_setprio(0);

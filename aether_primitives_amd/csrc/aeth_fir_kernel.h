@@ -58,6 +58,10 @@ enum : int {
                     // transform instead of one burst in front of it (the TA command FIFO is full 40 % of the time)
     V_DEMOD = 1024, // product variant: hard demodulation instead of the sample store (aeth_fft_mul_ifft_demod)
     V_DM_BPSK = 1 << 16, V_DM_QGEN = 1 << 17,   // with V_DEMOD: the decision's mode (neither: QPSK, separable table)
+    V_DMA = 1 << 18, // the next window goes straight into a 16 KiB LDS landing image (buffer_load_dwordx4 ... lds: 8 pieces
+                    // of 1 KiB per wave and block instead of 16 register loads) and is read from there at the start of its
+                    // own iteration: no prefetch registers, no register copy per block; paid for with ONE exchange image
+                    // (two barriers per exchange) so that four workgroups still fit a CU.  N = 2048 (two waves) only.
     V_NOLOAD = 16,  // diagnosis only (wrong output): no window loads inside the loop
     V_NOSTORE = 32, // diagnosis only (wrong output): no output stores inside the loop
     V_CENSUS = 256, // diagnosis only: every wave records HW_ID / XCC_ID in the buffer passed as `chirp`
@@ -181,6 +185,38 @@ __device__ __forceinline__ void load_window_srd_part(cf (&x)[C::P], const FmiArg
         x[m] = as_cf(__builtin_amdgcn_raw_buffer_load_b64(rs, (tid + m * C::T) * 8, 0, NT ? AETH_FIR_LOAD_AUX : 0));
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// ---- V_DMA: the window through an LDS landing image ---------------------------------------------------------
+// The image is lane-linear per wave-instruction (LDS dest = base + lane * 16), so the permutation sits on the SOURCE
+// side: piece j of wave wv fetches the 512-byte runs of window rows m = 2j and 2j+1 (a row = T elements = 1 KiB) that
+// this very wave reads in pass 0 (element tid + m*T).  No wave reads what another wave landed, so the issuing wave's
+// own vmcnt orders its ds_reads behind the DMA and no barrier is needed.  A lane past the descriptor's range lands
+// zeros (tools/shape_ab.hip, oob_probe), so the ragged end of the stream and a non-existent block need no branch.
+typedef __attribute__((address_space(3))) void *lds_vptr_t;
+template <bool NT>
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, cf *dst, int voff, int soff)
+{
+#if __HIP_DEVICE_COMPILE__
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)dst, 16, voff, soff, 0, NT ? AETH_FIR_LOAD_AUX : 0);
+#endif
+}
+template <class C, bool NT, int J0, int J1>
+__device__ __forceinline__ void dma_window_part(cf *land, const FmiArgs &a, long long blk, int tid)
+{
+    static_assert(C::T == 128 && C::P == 16, "landing image: two waves, sixteen rows of 1 KiB");
+    const bool active = blk < a.nblocks;
+    const long long win0 = active ? blk * a.hop - a.ov : 0;
+    long long left = a.n - win0;
+    const int bytes = active ? (int)(left < a.frame_n ? left : a.frame_n) * 8 : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.in + win0), 0, bytes, 0x00020000);
+    const int wv = tid >> 6, l = tid & 63;
+    const int voff = (l >> 5) * 1024 + wv * 512 + (l & 31) * 16;
+#pragma unroll
+    for (int j = J0; j < J1; j++) dma_piece<NT>(rs, land + wv * 1024 + j * 128, voff, j * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// slot of window element tid + m*T in the landing image (elements)
+template <class C> __device__ __forceinline__ int land_slot(int tid, int m) { return (tid >> 6) * 1024 + (m >> 1) * 128 + (m & 1) * 64 + (tid & 63); }
 
 // V_TOUCH: one dword per 128-byte line of block `blk`'s window (plain cache policy: the line is meant to stay on
 // the die until the register prefetch reads it); the value is never used, the caller only keeps it alive.
@@ -521,6 +557,65 @@ __global__ __launch_bounds__(C::WG, MINW) void fmi_kernel(FmiArgs a)
         else store_block<C, SCALED, NT, true, (VAR & V_DECIM) != 0>(w, a, blk, tid);
     }
     if constexpr (TOUCH) asm volatile("" ::"v"(tprev));
+}
+
+// ---- V_DMA build of the FIR kernel (N = 2048: two waves, sixteen 1 KiB window rows; unscaled, no chirp) ----------
+template <class C> struct OneImg : C { static constexpr bool DB = false; static constexpr int LDS_TOTAL = C::LDS_ELEMS; };
+
+template <class C0, bool NT, int VAR>
+__global__ __launch_bounds__(C0::WG, 1) void fmi_dma_kernel(FmiArgs a)
+{
+    using C = OneImg<C0>;
+    static_assert(C::F == 1 && C::T == 128 && C::P == 16 && C::NPASS == 3, "landing image layout: N = 2048");
+    static_assert(AETH_FIR_LAB || (VAR & ~V_PRODUCT_MASK) == 0, "lab-only kernel variant in a product build");
+    __shared__ __attribute__((aligned(1024))) cf lds_all[C::N + C::LDS_TOTAL];
+    cf *land = lds_all, *lds = lds_all + C::N;              // [landing image | one exchange image]
+    const int tid = (int)threadIdx.x;
+    constexpr int XP = ((VAR & V_PRIO) ? 1 : 0) | ((VAR & V_XOR) ? 8 : 0) | 16;     // raw barriers: a DMA is always in flight
+    cf tw[C::TW], H[C::P];
+    const long long g0 = blockIdx.x;
+    if (blockIdx.x == 0) {
+        // history / zero initial state: predicated register path, parked in the landing image in the DMA's layout
+        cf w0[C::P];
+        load_window<C, NT>(w0, a, 0, tid);
+#pragma unroll
+        for (int m = 0; m < C::P; m++) land[land_slot<C>(tid, m)] = w0[m];
+    } else dma_window_part<C, NT, 0, 8>(land, a, g0, tid);
+    if (a.twL) load_twiddles_lane<C>(tw, a.twL, tid);
+    else load_twiddles<C>(tw, a.twN, tid);
+#pragma unroll
+    for (int m = 0; m < C::P; m++) H[m] = a.Hf[tid + m * C::T];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // tables and the first window are in
+#pragma unroll 1
+    for (long long g = g0; g < a.nblocks; g += gridDim.x) {
+        cf w[C::P];
+#pragma unroll
+        for (int m = 0; m < C::P; m++) w[m] = land[land_slot<C>(tid, m)];
+        if (tid < a.ov - a.nhist) w[0] = mk(0.f, 0.f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the image is read out before the next window lands in it
+        __builtin_amdgcn_sched_barrier(0);
+        const long long gn = g + gridDim.x;
+        if constexpr (VAR & V_SPREAD) {
+            dma_window_part<C, NT, 0, 2>(land, a, gn, tid);
+            run_pass<C, 0, +1, 0, XP>(w, tw, lds, tid);
+            dma_window_part<C, NT, 2, 4>(land, a, gn, tid);
+            run_pass<C, 1, +1, 0, XP>(w, tw, lds, tid);
+            dma_window_part<C, NT, 4, 6>(land, a, gn, tid);
+            run_pass<C, 2, +1, 0, XP>(w, tw, lds, tid);
+#pragma unroll
+            for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);
+            dma_window_part<C, NT, 6, 8>(land, a, gn, tid);
+            fft_in_regs<C, -1, 0, XP>(w, tw, lds, tid);
+        } else {
+            dma_window_part<C, NT, 0, 8>(land, a, gn, tid);
+            fft_in_regs<C, +1, 0, XP>(w, tw, lds, tid);
+#pragma unroll
+            for (int m = 0; m < C::P; m++) w[m] = cmul(w[m], H[m]);
+            fft_in_regs<C, -1, 0, XP>(w, tw, lds, tid);
+        }
+        store_block<C, false, NT, false, false>(w, a, g, tid);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // the next window has landed; this block's 16 stores stay in flight
+    }
 }
 
 }  // namespace firk

@@ -65,7 +65,7 @@ int tuning_int(const char *name, int dflt);
 // kept.  They exist only in the lab build (`make LAB=1` -> lib/libaether_hip_lab.so, -DAETH_LAB=1); in the product
 // every lab_int() is its default at compile time, so the paths behind the other values are not in the library.
 #if defined(AETH_LAB) && AETH_LAB
-inline int lab_int(const char *name, int dflt) { return tuning_int(name, dflt); }
+#define lab_int tuning_int      /* the lab build reads them like any other knob */
 #else
 constexpr int lab_int(const char *, int dflt) { return dflt; }
 #endif

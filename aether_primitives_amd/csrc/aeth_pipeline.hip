@@ -25,6 +25,8 @@
 #include <sched.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -129,12 +131,23 @@ int pipe_prepare(aeth_ctx *ctx, size_t din_bytes, size_t dout_bytes, int nslots)
         if (!p->dout[s]) AETH_HIP(hipMalloc((void **)&p->dout[s], p->dout_bytes));
     }
     if (!p->team) {
-        // half of the cores this process may run on, 2 .. 12 (tuning: AETH_PIPE_THREADS).  Created BEFORE any staging
+        // three eighths of the cores this process may USE, 2 .. 12 (tuning: AETH_PIPE_THREADS).  Created BEFORE any staging
         // element is taken, so that no error path between the two leaves elements checked out.
         int hw = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) hw = c; }
-        int n = hw / 2; n = n < 2 ? 2 : (n > 12 ? 12 : n);
+        // a container's CPU quota counts, not the cores it can see: a one-GPU box shows 256 hardware threads and grants
+        // 16 -- twelve copy threads there get throttled and run at HALF the rate of six (profiles/r04_pipe_mixed_lab.txt:
+        // 68 ms against 48 ms for 256 Mi samples)
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long q = 0, per = 0; char buf[64] = {0};
+            if (fscanf(f, "%63s %lld", buf, &per) == 2 && strcmp(buf, "max") != 0 && per > 0 && (q = atoll(buf)) > 0) {
+                const int cpus = (int)((q + per - 1) / per);
+                if (cpus >= 1 && cpus < hw) hw = cpus;
+            }
+            fclose(f);
+        }
+        int n = hw * 3 / 8; n = n < 2 ? 2 : (n > 12 ? 12 : n);
         n = aeth::tuning_int("AETH_PIPE_THREADS", n);
         p->team = new (std::nothrow) aeth::CopyTeam(n);
         AETH_REQUIRE(p->team, AETH_E_NOMEM, "out of host memory");

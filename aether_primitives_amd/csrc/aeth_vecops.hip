@@ -212,9 +212,138 @@ int host_roundtrip(aeth_ctx *ctx, aeth_cf32 *self, size_t n, const aeth_cf32 *ot
     return AETH_OK;
 }
 
+// ---- a chain of element-wise steps in ONE pass over memory ------------------------------------------------------
+// The reference's VecOps are chainable (`v.vec_add(&a).vec_mul(&b).vec_conj()`, vecops.rs:12-38 and BASELINE config
+// 1): on the CPU every link is a pass over cache-resident data, on the device every link is a launch and a round trip
+// through HBM (C1: three launches, 24 + 24 + 16 = 64 B per sample).  aeth_vec_chain runs the links per element in
+// registers: `self` is read once and written once, every binary link reads its operand once (C1: 8 + 8 + 8 R + 8 W =
+// 32 B per sample, one launch).  Each link is the same rounded arithmetic as its own kernel (apply2 above, no
+// contraction), so the result is bit-identical to the separate calls.
+constexpr int kChainMax = 8;
+struct ChainArgs {
+    int n_steps;
+    int op[kChainMax];
+    const float2 *other[kChainMax];
+    float scale[kChainMax];
+};
+
+__device__ __forceinline__ float2 chain_step(int op, float2 a, float2 b, float s)
+{
+    switch (op) {                                           // wave-uniform: the program lives in the kernel arguments
+    case OP_ADD: return apply2<OP_ADD>(a, b, s);
+    case OP_SUB: return apply2<OP_SUB>(a, b, s);
+    case OP_MUL: return apply2<OP_MUL>(a, b, s);
+    case OP_DIV: return apply2<OP_DIV>(a, b, s);
+    case OP_SCALE: return apply2<OP_SCALE>(a, b, s);
+    case OP_CONJ: return apply2<OP_CONJ>(a, b, s);
+    case OP_CLONE: return b;
+    default: return make_float2(0.0f, 0.0f);
+    }
+}
+
+template <typename V, bool NT>
+__global__ __launch_bounds__(kBlock) void chain_kernel(V *__restrict__ self, size_t n, ChainArgs c, int read_self)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    V b[kChainMax];
+    V a;
+    // every load of the element goes out before the first link runs
+    if (read_self) a = aeth::nt_load<NT>(self + i);
+    else { if constexpr (sizeof(V) == 16) a = make_float4(0.f, 0.f, 0.f, 0.f); else a = make_float2(0.f, 0.f); }
+#pragma unroll
+    for (int k = 0; k < kChainMax; k++) {
+        if (k < c.n_steps && c.other[k]) b[k] = aeth::nt_load<NT>(reinterpret_cast<const V *>(c.other[k]) + i);
+        else { if constexpr (sizeof(V) == 16) b[k] = make_float4(0.f, 0.f, 0.f, 0.f); else b[k] = make_float2(0.f, 0.f); }
+    }
+#pragma unroll
+    for (int k = 0; k < kChainMax; k++) {
+        if (k < c.n_steps) {
+            if constexpr (sizeof(V) == 16) {
+                const float2 lo = chain_step(c.op[k], make_float2(a.x, a.y), make_float2(b[k].x, b[k].y), c.scale[k]);
+                const float2 hi = chain_step(c.op[k], make_float2(a.z, a.w), make_float2(b[k].z, b[k].w), c.scale[k]);
+                a = make_float4(lo.x, lo.y, hi.x, hi.y);
+            } else a = chain_step(c.op[k], a, b[k], c.scale[k]);
+        }
+    }
+    aeth::nt_store<NT>(self + i, a);
+}
+
+int launch_chain(aeth_ctx *ctx, float2 *self, size_t n, const ChainArgs &c)
+{
+    aeth::DeviceGuard dev_guard(ctx->device);
+    const int read_self = !(c.op[0] == OP_CLONE || c.op[0] == OP_ZERO);
+    size_t operands = 1 + (read_self ? 1 : 0);
+    bool same_phase = true;
+    const uintptr_t ma = reinterpret_cast<uintptr_t>(self) & 15u;
+    for (int k = 0; k < c.n_steps; k++)
+        if (c.other[k]) { operands++; same_phase = same_phase && (reinterpret_cast<uintptr_t>(c.other[k]) & 15u) == ma; }
+    const bool nt = aeth::streams_past_cache(n * sizeof(float2) * operands);
+    auto shifted = [&](size_t off) { ChainArgs d = c; for (int k = 0; k < c.n_steps; k++) if (d.other[k]) d.other[k] += off; return d; };
+    auto one = [&](size_t off, size_t cnt) {                                            // 8-byte lanes
+        auto kern = nt ? chain_kernel<float2, true> : chain_kernel<float2, false>;
+        hipLaunchKernelGGL(kern, dim3(grid_for(ctx, cnt)), dim3(kBlock), 0, aeth::ctx_stream(ctx), self + off, cnt, shifted(off), read_self);
+    };
+    if (same_phase) {
+        const size_t head = (ma != 0) ? 1 : 0, body = (n - head) / 2, tail = (n - head) - 2 * body;
+        if (head) one(0, 1);
+        if (body) {
+            auto kern = nt ? chain_kernel<float4, true> : chain_kernel<float4, false>;
+            hipLaunchKernelGGL(kern, dim3(grid_for(ctx, body)), dim3(kBlock), 0, aeth::ctx_stream(ctx), reinterpret_cast<float4 *>(self + head), body,
+                               shifted(head), read_self);
+        }
+        if (tail) one(head + 2 * body, 1);
+    } else one(0, n);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+/* `self.vec_a(..).vec_b(..) ...` (vecops.rs:12-38) as one pass: see chain_kernel above */
+int aeth_vec_chain(aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_vec_step *steps, size_t n_steps)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    AETH_REQUIRE(steps || n_steps == 0, AETH_E_ARG, "steps is null");
+    static const int kOps[8] = {OP_SCALE, OP_MUL, OP_DIV, OP_CONJ, OP_ADD, OP_SUB, OP_CLONE, OP_ZERO};      /* AETH_VEC_* order */
+    // every link's own checks first (the reference would panic at that link: vecops.rs:100-104 etc.)
+    for (size_t k = 0; k < n_steps; k++) {
+        const aeth_vec_step &st = steps[k];
+        AETH_REQUIRE(st.op >= 0 && st.op < 8, AETH_E_ARG, "step %zu: unknown op %d", k, st.op);
+        const int op = kOps[st.op];
+        if (op == OP_ADD || op == OP_SUB || op == OP_MUL || op == OP_DIV || op == OP_CLONE) {
+            AETH_REQUIRE(st.n_other == n, AETH_E_LEN, AETH_MSG_VEC_LEN);
+            if (n) {
+                AETH_REQUIRE(st.other_dev, AETH_E_ARG, "step %zu: null operand", k);
+                AETH_REQUIRE(aeth::aligned8(st.other_dev), AETH_E_ALIGN, "pointer not 8-byte aligned");
+                // a link reads its operand as it was BEFORE the chain: an operand that overlaps `self` would see the
+                // original samples where the separate calls see modified ones (Rust cannot express that call anyway)
+                const uintptr_t a0 = (uintptr_t)self_, a1 = a0 + n * sizeof(aeth_cf32), b0 = (uintptr_t)st.other_dev, b1 = b0 + n * sizeof(aeth_cf32);
+                AETH_REQUIRE(a1 <= b0 || b1 <= a0, AETH_E_ARG, "step %zu: the operand overlaps self", k);
+            }
+        }
+    }
+    if (n == 0 || n_steps == 0) return AETH_OK;
+    AETH_REQUIRE(self_, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(self_), AETH_E_ALIGN, "pointer not 8-byte aligned");
+    for (size_t k0 = 0; k0 < n_steps; k0 += kChainMax) {                  /* longer chains: kChainMax links per pass */
+        ChainArgs c;
+        c.n_steps = (int)(n_steps - k0 < (size_t)kChainMax ? n_steps - k0 : (size_t)kChainMax);
+        for (int k = 0; k < kChainMax; k++) { c.op[k] = OP_ZERO; c.other[k] = nullptr; c.scale[k] = 0.f; }
+        for (int k = 0; k < c.n_steps; k++) {
+            const aeth_vec_step &st = steps[k0 + k];
+            c.op[k] = kOps[st.op];
+            const bool bin = c.op[k] == OP_ADD || c.op[k] == OP_SUB || c.op[k] == OP_MUL || c.op[k] == OP_DIV || c.op[k] == OP_CLONE;
+            c.other[k] = bin ? reinterpret_cast<const float2 *>(st.other_dev) : nullptr;
+            c.scale[k] = st.scale;
+        }
+        int rc = launch_chain(ctx, reinterpret_cast<float2 *>(self_), n, c);
+        if (rc) return rc;
+    }
+    return AETH_OK;
+}
 
 int aeth_vec_scale(aeth_ctx *ctx, aeth_cf32 *x, size_t n, float s)
 {

@@ -372,9 +372,9 @@ def criterion_shapes(args):
     # vec ops @ 2048 (benches.rs:30-67)
     a, b = ap.HostVec(ctx, ones(2048)), ap.HostVec(ctx, ones(2048))
     da, db = ctx.vec(ones(2048)), ctx.vec(ones(2048))
-    row("vec_mul 2048", "benches.rs:37", cpu(0, 2048), lambda: a.vec_mul(b), lambda: da.vec_mul(db))
+    row("vec_mul 2048", "benches.rs:37", cpu(0, 2048), lambda: a.vec_mul(b.a), lambda: da.vec_mul(db))
     row("vec_scale 2048", "benches.rs:48", cpu(1, 2048), lambda: a.vec_scale(1.0), lambda: da.vec_scale(1.0))
-    row("vec_clone 2048", "benches.rs:59", cpu(2, 2048), lambda: a.vec_clone(b), lambda: da.vec_clone(db))
+    row("vec_clone 2048", "benches.rs:59", cpu(2, 2048), lambda: a.vec_clone(b.a), lambda: da.vec_clone(db))
     # interpolate (len, n_between): the bench passes n_between = 4 whatever the tuple says (benches.rs:88)
     for n in (1024, 2048, 400):
         src = (np.arange(n) + 0j).astype(np.complex64); dsrc = ctx.vec(src); ddst = ctx.empty(n + (n - 1) * 4)
@@ -394,7 +394,7 @@ def criterion_shapes(args):
         row(f"fft fwd SN copy {n}", "benches.rs:340-357", cpu(6, n), lambda: f.fwd(x, y, Scale.SN), lambda: f.fwd(dx, dy, Scale.SN))
         hx = ap.HostVec(ctx, x); hs = ap.HostVec(ctx, ones(n))
         row(f"correlator chain {n}", "benches.rs:388-420", cpu(7, n),
-            lambda: hx.vec_rfft(f, Scale.NONE).vec_mul(hs).vec_rifft(f, Scale.NONE), lambda: f.mul_chain(dx, sigd))
+            lambda: hx.vec_rfft(f, Scale.NONE).vec_mul(hs.a).vec_rifft(f, Scale.NONE), lambda: f.mul_chain(dx, sigd))
     # modulation (benches.rs:210-278)
     q = modulation.qpsk(ctx)
     for n in (100, 8000):

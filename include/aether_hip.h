@@ -81,7 +81,8 @@ enum { AETH_SIGN_REF_FWD = +1, AETH_SIGN_REF_BWD = -1 };
  *   AETH_FIR_SPREAD        0 / 1: force the burst / spread form of the next-window prefetch (default: spread for a
  *                          lone launch, burst beside another)
  *   AETH_NT                0 / 1: force plain / non-temporal accesses on streamed operands (default: by size)
- *   AETH_PIPE_THREADS      host copy threads of the stream pipeline (default: half the cores the process may use, 2..12)
+ *   AETH_PIPE_THREADS      host copy threads of the stream pipeline (default: 3/8 of the cores the process may use -- affinity mask and
+ *                          cgroup CPU quota --, 2..12)
  *   AETH_PIPE_MIXED        1: a pageable input next to a pinned output downloads directly into the caller's memory
  *                          (default 0: both sides staged -- the mixed form measured 2.4 x slower downloads)
  *   AETH_SYNC_SPIN_US      how long aeth_ctx_sync polls both queues before it blocks (default 2000) */
@@ -144,6 +145,16 @@ AETH_API int aeth_vec_mirror_frames(aeth_ctx *ctx, aeth_cf32 *self_, size_t fram
 AETH_API int aeth_vec_mul_frames(aeth_ctx *ctx, aeth_cf32 *frames, size_t frame_len, size_t batch,
                                  const aeth_cf32 *sig, size_t n_sig);
 /* vec_mutate (:179-182) takes a Rust closure and stays on the host side of the binding. */
+/* A CHAIN of the element-wise methods above in one pass over memory: `v.vec_add(&a).vec_mul(&b).vec_conj()` (the
+ * reference's chaining, src/vecops.rs:12-38; BASELINE config 1) reads `self_` once, every binary link's operand once,
+ * and writes `self_` once -- one launch and 32 B per sample for that chain instead of three launches and 64 B.  Each
+ * link is its own kernel's arithmetic, rounded link by link: bit-identical to the separate calls.  Per link the checks
+ * of its own entry point ("Vectors must have same length"); an operand that overlaps self_ is refused (AETH_E_ARG).
+ * vec_mirror (a permutation) and vec_mutate (a closure) are not links.  Any number of steps (8 per pass). */
+enum { AETH_VEC_SCALE = 0, AETH_VEC_MUL = 1, AETH_VEC_DIV = 2, AETH_VEC_CONJ = 3, AETH_VEC_ADD = 4, AETH_VEC_SUB = 5,
+       AETH_VEC_CLONE = 6, AETH_VEC_ZERO = 7 };
+typedef struct aeth_vec_step { int op; const aeth_cf32 *other_dev; size_t n_other; float scale; } aeth_vec_step;
+AETH_API int aeth_vec_chain(aeth_ctx *ctx, aeth_cf32 *self_, size_t n, const aeth_vec_step *steps, size_t n_steps);
 
 /* ---- VecOps, host-slice flavour (synchronous) ----------------------------- */
 AETH_API int aeth_host_vec_scale (aeth_ctx *ctx, aeth_cf32 *self_, size_t n, float scale);

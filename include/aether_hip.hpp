@@ -127,6 +127,25 @@ public:
     inline DeviceVec &vec_rfft(HipFft &fft, Scale s);      // reused plan (src/vecops.rs:198-207)
     inline DeviceVec &vec_rifft(HipFft &fft, Scale s);
 
+    // A chain of the element-wise methods in ONE pass over memory (aeth_vec_chain): v.fused().vec_add(a).vec_mul(b).vec_conj().run()
+    class Chain {
+    public:
+        explicit Chain(DeviceVec &v) : v_(v) {}
+        Chain &vec_scale(float s) { steps_.push_back({AETH_VEC_SCALE, nullptr, 0, s}); return *this; }
+        Chain &vec_mul(const DeviceVec &o) { return bin(AETH_VEC_MUL, o); }
+        Chain &vec_div(const DeviceVec &o) { return bin(AETH_VEC_DIV, o); }
+        Chain &vec_conj() { steps_.push_back({AETH_VEC_CONJ, nullptr, 0, 0.f}); return *this; }
+        Chain &vec_add(const DeviceVec &o) { return bin(AETH_VEC_ADD, o); }
+        Chain &vec_sub(const DeviceVec &o) { return bin(AETH_VEC_SUB, o); }
+        Chain &vec_clone(const DeviceVec &o) { return bin(AETH_VEC_CLONE, o); }
+        Chain &vec_zero() { steps_.push_back({AETH_VEC_ZERO, nullptr, 0, 0.f}); return *this; }
+        DeviceVec &run() { check(aeth_vec_chain(v_.c(), v_.ptr(), v_.len(), steps_.data(), steps_.size())); steps_.clear(); return v_; }
+    private:
+        Chain &bin(int op, const DeviceVec &o) { steps_.push_back({op, o.ptr(), o.len(), 0.f}); return *this; }
+        DeviceVec &v_;
+        std::vector<aeth_vec_step> steps_;
+    };
+    Chain fused() { return Chain(*this); }
 private:
     aeth_ctx *c() const { return ctx_->get(); }
     Context *ctx_;

@@ -12,6 +12,12 @@ pub const AETH_POOL_ZERO_ON_RETURN: c_int = 1;
 /// aeth_pipe_stats: what the three-stage host-stream pipeline reports
 #[repr(C)] #[derive(Default, Clone, Copy)]
 pub struct aeth_pipe_stats { pub seconds: f64, pub samples: f64, pub chunks: f64, pub pinned: f64 }
+/// aeth_vec_step: one link of aeth_vec_chain (op = AETH_VEC_*)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct aeth_vec_step { pub op: c_int, pub other_dev: *const cf32, pub n_other: usize, pub scale: c_float }
+pub const AETH_VEC_SCALE: c_int = 0; pub const AETH_VEC_MUL: c_int = 1; pub const AETH_VEC_DIV: c_int = 2; pub const AETH_VEC_CONJ: c_int = 3;
+pub const AETH_VEC_ADD: c_int = 4; pub const AETH_VEC_SUB: c_int = 5; pub const AETH_VEC_CLONE: c_int = 6; pub const AETH_VEC_ZERO: c_int = 7;
 /// aeth_stream_op: the compute stage of the host pipeline (src/pipeline.rs:24-41 takes a closure; a closure cannot
 /// cross the C ABI, so the stage is one of the library's device ops, described field by field as in aether_hip.h)
 #[repr(C)]
@@ -133,6 +139,7 @@ extern "C" {
     pub fn aeth_host_register(ctx: *mut aeth_ctx, ptr: *mut c_void, bytes: usize) -> c_int;
     pub fn aeth_host_unregister(ctx: *mut aeth_ctx, ptr: *mut c_void) -> c_int;
     pub fn aeth_host_is_pinned(ptr: *const c_void, bytes: usize) -> c_int;
+    pub fn aeth_vec_chain(ctx: *mut aeth_ctx, self_: *mut cf32, n: usize, steps: *const aeth_vec_step, n_steps: usize) -> c_int;
     pub fn aeth_stream_out_count(ctx: *mut aeth_ctx, op: *const aeth_stream_op, n_in: usize) -> usize;
     pub fn aeth_stream_host(ctx: *mut aeth_ctx, op: *const aeth_stream_op, inp: *const c_void, n_in: usize, out: *mut c_void,
                             n_out: usize, chunk: usize, stats: *mut aeth_pipe_stats) -> c_int;

@@ -124,6 +124,10 @@ impl<'c> DeviceVec<'c> {
         check(unsafe { aeth_upload(self.ctx.h, self.p as *mut c_void, v.as_ptr() as *const c_void, self.n * 8) });
         self
     }
+    /// the chained element-wise methods as ONE pass over memory (`aeth_vec_chain`; bit-identical to the separate calls):
+    /// `v.fused().vec_add(&a).vec_mul(&b).vec_conj().run();` -- the operands are borrowed until `run`, so the borrow
+    /// checker rules out an operand that aliases `self` exactly as it does for the separate calls
+    pub fn fused<'v>(&'v mut self) -> Chain<'v, 'c> { Chain { v: self, steps: Vec::new() } }
     /// device frames through a plan: `len()` may be a multiple of `fft.len()` (a batch)
     pub fn vec_rfft(&mut self, fft: &mut HipFft, s: Scale) -> &mut Self { self.exec(fft, AETH_SIGN_REF_FWD, s) }
     pub fn vec_rifft(&mut self, fft: &mut HipFft, s: Scale) -> &mut Self { self.exec(fft, AETH_SIGN_REF_BWD, s) }
@@ -135,6 +139,22 @@ impl<'c> DeviceVec<'c> {
     }
 }
 impl<'c> Drop for DeviceVec<'c> { fn drop(&mut self) { unsafe { aeth_dev_free(self.ctx.h, self.p as *mut c_void); } } }
+
+/// links recorded by `DeviceVec::fused()`
+pub struct Chain<'v, 'c> { v: &'v mut DeviceVec<'c>, steps: Vec<aeth_vec_step> }
+impl<'v, 'c> Chain<'v, 'c> {
+    fn un(mut self, op: c_int, scale: f32) -> Self { self.steps.push(aeth_vec_step { op, other_dev: ptr::null(), n_other: 0, scale }); self }
+    fn bin(mut self, op: c_int, o: &'v DeviceVec) -> Self { self.steps.push(aeth_vec_step { op, other_dev: o.p, n_other: o.n, scale: 0.0 }); self }
+    pub fn vec_scale(self, s: f32) -> Self { self.un(AETH_VEC_SCALE, s) }
+    pub fn vec_conj(self) -> Self { self.un(AETH_VEC_CONJ, 0.0) }
+    pub fn vec_zero(self) -> Self { self.un(AETH_VEC_ZERO, 0.0) }
+    pub fn vec_mul(self, o: &'v DeviceVec) -> Self { self.bin(AETH_VEC_MUL, o) }
+    pub fn vec_div(self, o: &'v DeviceVec) -> Self { self.bin(AETH_VEC_DIV, o) }
+    pub fn vec_add(self, o: &'v DeviceVec) -> Self { self.bin(AETH_VEC_ADD, o) }
+    pub fn vec_sub(self, o: &'v DeviceVec) -> Self { self.bin(AETH_VEC_SUB, o) }
+    pub fn vec_clone(self, o: &'v DeviceVec) -> Self { self.bin(AETH_VEC_CLONE, o) }
+    pub fn run(self) { check(unsafe { aeth_vec_chain(self.v.ctx.h, self.v.p, self.v.n, self.steps.as_ptr(), self.steps.len()) }); }
+}
 
 pub mod sampling {
     use super::*;

@@ -102,7 +102,7 @@ def test_stream_from_and_into_pool_elements(ctx, plan, sig):
         _, st = pipeline.run(pipeline.Stage.correlate_demod(plan, sig, 2), xin, out=bits, chunk=N * 10)
         want = modulation.qpsk(ctx).correlate_demod(plan, ctx.vec(x), sig).to_host()
         assert st["pinned"] == 3 and np.array_equal(bits, want)
-        del xin, bits
+        del xin, bits, _                                           # `_` is the output array run() returned
     p.close()
 
 

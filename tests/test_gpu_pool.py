@@ -117,7 +117,7 @@ def test_stream_from_pool_elements_is_direct_and_bit_identical(ctx, n):
         y[:] = 0
         _, st = f.filter_stream(x, out=y)                      # a staged input takes the output through the host stage too
         assert st["pinned"] == 0 and bits_equal(y, want)
-        del xin, y
+        del xin, y, _                                          # `_` is the array filter_stream returned
     z, st = f.filter_stream(x, report=True)
     assert st["pinned"] == 0 and bits_equal(z, want)
     assert st["active_copy_in"] > 0 and st["active_copy_out"] > 0 and len(st["lines"]) == 5

@@ -149,3 +149,69 @@ def test_scale_kat_and_apply(ctx):
         s = {"None": ap.Scale.NONE, "SN": ap.Scale.SN, "N": ap.Scale.N}.get(c["scale"]) or ap.Scale.X(c["x"])
         s.scale(v)
         ap.assert_evm(v.to_host(), expand(c["expect"]), c["evm_db"])
+
+
+# ---- the chained methods as one pass over memory (aeth_vec_chain) -----------------------------------------------------
+def _apply_chain(oracle, v, links):
+    for name, arg in links:
+        v = getattr(oracle, name)(v, arg) if arg is not None else getattr(oracle, name)(v)
+    return v
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 4096, 100003, 1 << 20])
+def test_fused_chain_is_the_separate_calls_bit_for_bit(ctx, oracle, n):
+    """BASELINE config 1's chain (add -> mul -> conj) and a longer one with every link kind, against the oracle applied
+    link by link and against the same chain as separate device calls"""
+    v, a, b, c = (rand_c64(s + n, n) for s in (1, 2, 3, 4))
+    da, db, dc = ctx.vec(a), ctx.vec(b), ctx.vec(c)
+    got = ctx.vec(v).fused().vec_add(da).vec_mul(db).vec_conj().run().to_host()
+    assert bits_equal(got, oracle.vec_conj(oracle.vec_mul(oracle.vec_add(v, a), b)))
+    assert bits_equal(got, ctx.vec(v).vec_add(da).vec_mul(db).vec_conj().to_host())
+    links = [("vec_scale", 0.37), ("vec_div", b), ("vec_sub", c), ("vec_conj", None), ("vec_mul", a), ("vec_add", c), ("vec_scale", -2.5), ("vec_div", a)]
+    dev = {id(a): da, id(b): db, id(c): dc}
+    ch = ctx.vec(v).fused()
+    for name, arg in links:
+        ch = getattr(ch, name)(dev[id(arg)]) if isinstance(arg, np.ndarray) else (getattr(ch, name)(arg) if arg is not None else getattr(ch, name)())
+    assert bits_equal(ch.run().to_host(), _apply_chain(oracle, v, links))
+
+
+def test_fused_chain_longer_than_one_pass_and_overwriting_links(ctx, oracle):
+    n = 5000
+    v, a, b = rand_c64(1, n), rand_c64(2, n), rand_c64(3, n)
+    da, db = ctx.vec(a), ctx.vec(b)
+    ch = ctx.vec(v).fused()
+    want = v
+    for k in range(19):                                     # 19 links: three passes of at most eight
+        if k % 3 == 0: ch = ch.vec_add(da); want = oracle.vec_add(want, a)
+        elif k % 3 == 1: ch = ch.vec_scale(0.75); want = oracle.vec_scale(want, 0.75)
+        else: ch = ch.vec_mul(db); want = oracle.vec_mul(want, b)
+    assert bits_equal(ch.run().to_host(), want)
+    # clone / zero in front: self is not even read
+    assert bits_equal(ctx.vec(v).fused().vec_clone(da).vec_mul(db).run().to_host(), oracle.vec_mul(a, b))
+    assert bits_equal(ctx.vec(v).fused().vec_zero().vec_add(db).run().to_host(), oracle.vec_add(np.zeros(n, np.complex64), b))
+    assert bits_equal(ctx.vec(v).fused().vec_add(da).vec_zero().run().to_host(), np.zeros(n, np.complex64))
+    with ctx.vec(v).fused() as f:                           # the `with` form runs on exit
+        f.vec_conj()
+    assert bits_equal(f.vec.to_host(), oracle.vec_conj(v))
+    assert bits_equal(ctx.vec(v).fused().run().to_host(), v)            # an empty chain does nothing
+
+
+def test_fused_chain_on_misaligned_views(ctx, oracle):
+    a, b, c = rand_c64(1, 6001), rand_c64(2, 6001), rand_c64(3, 6001)
+    for sa, sb, sc in [(1, 1, 1), (1, 0, 1), (0, 1, 0), (3, 2, 5)]:
+        n = 5000
+        da, db, dc = ctx.vec(a), ctx.vec(b), ctx.vec(c)
+        da.slice(sa, sa + n).fused().vec_mul(db.slice(sb, sb + n)).vec_sub(dc.slice(sc, sc + n)).run()
+        expect = a.copy(); expect[sa:sa + n] = oracle.vec_sub(oracle.vec_mul(a[sa:sa + n], b[sb:sb + n]), c[sc:sc + n])
+        assert bits_equal(da.to_host(), expect)
+
+
+def test_fused_chain_errors(ctx):
+    v, short = ctx.vec(rand_c64(1, 100)), ctx.vec(rand_c64(2, 99))
+    with pytest.raises(ap.LengthMismatch, match="Vectors must have same length"):
+        v.fused().vec_conj().vec_mul(short).run()           # the link that would have panicked in the reference
+    with pytest.raises(ap.AetherError, match="overlaps self"):
+        v.fused().vec_add(v.slice(0, 100)).run()
+    big = ctx.vec(rand_c64(3, 300))
+    with pytest.raises(ap.AetherError, match="overlaps self"):
+        big.slice(0, 200).fused().vec_mul(big.slice(100, 300)).run()

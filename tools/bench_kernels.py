@@ -57,6 +57,13 @@ for N in (512, 1024, 2048, 4096, 12, 100, 126, 143, 960, 1000, 1536, 3600, 6000,
     m = (n // N) * N
     report(f"fft ifwd N={N} batch={m // N} ({f.algorithm})", 16 * m, timeit(lambda i: f.ifwd(A[i % NB].slice(0, m), Scale.SN)), m)
 f = ap.HipFft(ctx, 2048)
+# round 4: the chained methods in one pass (aeth_vec_chain) -- BASELINE config 1's chain on HBM-sized operands and on 4096 samples
+c3 = [ctx.vec(host[:n]) for _ in range(3)]
+report("chain add->mul->conj, three calls (64 B/sample)", 64 * n, timeit(lambda i: A[i % NB].vec_add(c3[0]).vec_mul(c3[1]).vec_conj()), n)
+report("chain add->mul->conj, fused (32 B/sample)", 32 * n, timeit(lambda i: A[i % NB].fused().vec_add(c3[0]).vec_mul(c3[1]).vec_conj().run()), n)
+s4 = [ctx.vec(host[:4096]) for _ in range(3)]
+report("C1 literal: chain on 4096 samples, three calls", 64 * 4096, timeit(lambda i: s4[0].vec_add(s4[1]).vec_mul(s4[2]).vec_conj(), reps=200), 4096)
+report("C1 literal: chain on 4096 samples, fused", 32 * 4096, timeit(lambda i: s4[0].fused().vec_add(s4[1]).vec_mul(s4[2]).vec_conj().run(), reps=200), 4096)
 report("fft fwd (out of place) N=2048", 16 * n, timeit(lambda i: f.fwd(A[i % NB], B[i % NB], Scale.SN)), n)
 c2 = [ctx.vec(host[:1 << 20]) for _ in range(2)]
 report("C2 literal: fft-2048 ifwd on 1 Mi samples (8 MiB)", 16 * (1 << 20), timeit(lambda i: f.ifwd(c2[i % 2], Scale.SN), reps=50), 1 << 20)

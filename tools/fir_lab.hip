@@ -57,9 +57,17 @@ static void launch_var(const FmiArgs &a, int grid, hipStream_t s, int any_order)
     }
 }
 
+template <int VAR>
+static void launch_dma(const FmiArgs &a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((fmi_dma_kernel<C2048, true, VAR>), dim3(grid), dim3(C2048::WG), 0, s, a);
+}
+
 static void launch(int var, const FmiArgs &a, int grid, hipStream_t s, int any_order)
 {
     switch (var) {
+    case (1 << 18) + 2052: launch_dma<2052>(a, grid, s); break;
+    case (1 << 18) + 18436: launch_dma<18436>(a, grid, s); break;
     case 1000: launch_var2<0>(a, grid, s); break;
     case 1048: launch_var2<48>(a, grid, s); break;
     case 1176: launch_var2<176>(a, grid, s); break;
@@ -130,6 +138,9 @@ int main(int argc, char **argv)
         {"xor+prio/g768/2q", 2052, 2, 768}, {"xor+prio/g896/2q", 2052, 2, 896}, {"xor+prio/g768", 2052, 0, 768},
         {"xor+prio/g704/2q", 2052, 2, 704}, {"xor+prio/g736/2q", 2052, 2, 736}, {"xor+prio/g800/2q", 2052, 2, 800},
         {"xor+prio/g832/2q", 2052, 2, 832}, {"xor+prio/g960/2q", 2052, 2, 960},
+        // round 4: the window through an LDS landing image (V_DMA), burst and spread, one queue and two
+        {"dma", (1 << 18) + 2052, 0, 0}, {"dma/2q", (1 << 18) + 2052, 2, 0}, {"dma/g768/2q", (1 << 18) + 2052, 2, 768},
+        {"dma+spread", (1 << 18) + 18436, 0, 0}, {"dma+spread/2q", (1 << 18) + 18436, 2, 0}, {"dma+spread/g768/2q", (1 << 18) + 18436, 2, 768},
         // round 4: 8457 blocks = 11 x 768 + 9 -- grids that divide the stream into whole rounds (769: 11 rounds, 705: 12, 846: 10)
         {"xor+prio/g769/2q", 2052, 2, 769}, {"xor+prio/g705/2q", 2052, 2, 705}, {"xor+prio/g846/2q", 2052, 2, 846},
         {"nolds/2q", 128, 2, 0}, {"prio/2q", 4, 2, 0}, {"peel/2q", 1, 2, 0},
