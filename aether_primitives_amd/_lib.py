@@ -107,6 +107,7 @@ PROTOTYPES = {
     "aeth_fir_stream_host": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_fir_stream_host_util": (i32, [vp, vp, sz, vp, sz, vp]),
     "aeth_fir_stream_file": (i32, [vp, C.c_char_p, C.c_char_p, sz, vp]),
+    "aeth_stream_file": (i32, [vp, vp, C.c_char_p, C.c_char_p, sz, vp]),
     "aeth_file_count_structs": (i32, [C.c_char_p, sz, psz]),
     "aeth_file_read": (i32, [C.c_char_p, sz, vp, sz, sz]),
     "aeth_file_write": (i32, [C.c_char_p, vp, sz, sz, i32]),

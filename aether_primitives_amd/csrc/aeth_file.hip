@@ -6,6 +6,7 @@
 // that is byte for byte the layout of a device buffer, so a recorded IQ stream can be
 // mapped and pushed through the GPU without any conversion.
 #include "aeth_internal.h"
+#include "aeth_fft_plan.h"
 
 #include <cerrno>
 #include <cstdio>
@@ -54,14 +55,15 @@ int aeth_file_write(const char *path, const void *src, size_t n, size_t elem_siz
     return rc;
 }
 
-/* raw cf32 file -> FIR -> raw cf32 file: both files are mapped and handed to the
- * double-buffered host-stream pipeline (aeth_fir_stream_host) */
-int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_path, size_t chunk, aeth_pipe_stats *stats)
+/* raw cf32 file -> one of the pipeline's ops -> raw file (cf32 samples, or bit bytes for the demodulating stage): both
+ * files are mapped and handed to the host-stream pipeline (aeth_stream_host) */
+int aeth_stream_file(aeth_ctx *ctx, const aeth_stream_op *op, const char *in_path, const char *out_path, size_t chunk,
+                     aeth_pipe_stats *stats)
 {
-    AETH_REQUIRE(fir && in_path && out_path, AETH_E_ARG, "null argument");
+    AETH_REQUIRE(ctx && op && in_path && out_path, AETH_E_ARG, "null argument");
     if (stats) *stats = aeth_pipe_stats{0, 0, 0, 0};
     // the input is opened, measured and mapped BEFORE the output is created or truncated, and a path that names
-    // the same file twice is refused: truncating the recording before reading it would filter zeros
+    // the same file twice is refused: truncating the recording before reading it would process zeros
     int fi = open(in_path, O_RDONLY);
     AETH_REQUIRE(fi >= 0, AETH_E_ARG, "%s: %s", in_path, strerror(errno));
     struct stat si;
@@ -69,7 +71,7 @@ int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_pat
     struct stat so;
     if (stat(out_path, &so) == 0 && so.st_dev == si.st_dev && so.st_ino == si.st_ino) {
         close(fi);
-        return aeth::set_error(AETH_E_ARG, "%s and %s are the same file: the FIR cannot run in place", in_path, out_path);
+        return aeth::set_error(AETH_E_ARG, "%s and %s are the same file: the stream cannot run in place", in_path, out_path);
     }
     if ((size_t)si.st_size % sizeof(aeth_cf32) != 0) {
         close(fi);
@@ -77,6 +79,10 @@ int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_pat
     }
     const size_t n = (size_t)si.st_size / sizeof(aeth_cf32);
     const size_t bytes = n * sizeof(aeth_cf32);
+    const size_t n_out = aeth_stream_out_count(ctx, op, n);
+    const size_t out_unit = op->kind == AETH_STREAM_FFT_MUL_IFFT_DEMOD ? 1 : sizeof(aeth_cf32);
+    const size_t obytes = n_out * out_unit;
+    if (n > 0 && n_out == 0) { close(fi); return aeth::set_error(AETH_E_ARG, "bad stream op"); }
     void *mi = MAP_FAILED, *mo = MAP_FAILED;
     int rc = AETH_OK;
     if (n > 0) {
@@ -86,18 +92,27 @@ int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_pat
     int fo = open(out_path, O_RDWR | O_CREAT | O_TRUNC, 0644);
     if (fo < 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", out_path, strerror(errno));
     if (rc == AETH_OK && n > 0) {
-        if (ftruncate(fo, (off_t)bytes) != 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", out_path, strerror(errno));
+        if (ftruncate(fo, (off_t)obytes) != 0) rc = aeth::set_error(AETH_E_ARG, "%s: %s", out_path, strerror(errno));
         if (rc == AETH_OK) {
-            mo = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fo, 0);
+            mo = mmap(nullptr, obytes, PROT_READ | PROT_WRITE, MAP_SHARED, fo, 0);
             if (mo == MAP_FAILED) rc = aeth::set_error(AETH_E_NOMEM, "mmap %s: %s", out_path, strerror(errno));
         }
-        if (rc == AETH_OK) rc = aeth_fir_stream_host(fir, (const aeth_cf32 *)mi, n, (aeth_cf32 *)mo, chunk, stats);
+        if (rc == AETH_OK) rc = aeth_stream_host(ctx, op, mi, n, mo, n_out, chunk, stats);
     }
     if (mi != MAP_FAILED) munmap(mi, bytes);
-    if (mo != MAP_FAILED) { msync(mo, bytes, MS_SYNC); munmap(mo, bytes); }
+    if (mo != MAP_FAILED) { msync(mo, obytes, MS_SYNC); munmap(mo, obytes); }
     close(fi);
     if (fo >= 0) close(fo);
     return rc;
+}
+
+/* raw cf32 file -> FIR -> raw cf32 file */
+int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_path, size_t chunk, aeth_pipe_stats *stats)
+{
+    AETH_REQUIRE(fir && in_path && out_path, AETH_E_ARG, "null argument");
+    aeth_stream_op op{};
+    op.kind = AETH_STREAM_FIR; op.fir = fir;
+    return aeth_stream_file(fir->ctx, &op, in_path, out_path, chunk, stats);
 }
 
 }  // extern "C"

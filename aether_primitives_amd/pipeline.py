@@ -97,3 +97,11 @@ def run(stage, x, out=None, chunk=0, report=False):
     check(lib.aeth_stream_host(stage.ctx.h, C.byref(stage.op), x.ctypes.data_as(C.c_void_p), x.size,
                                out.ctypes.data_as(C.c_void_p), out.size, chunk, C.byref(s)))
     return out, {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+
+def run_file(stage, in_path, out_path, chunk=0):
+    """raw cf32 file (src/util/file.rs format) -> stage -> raw file of the stage's output type; returns the stats"""
+    import os
+    s = _Stats()
+    check(_lib.load().aeth_stream_file(stage.ctx.h, C.byref(stage.op), os.fsencode(in_path), os.fsencode(out_path), chunk, C.byref(s)))
+    return {k: getattr(s, k) for k, _ in _Stats._fields_}

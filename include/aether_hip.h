@@ -346,7 +346,11 @@ AETH_API void aeth_test_fail_staging_after(int n);
 AETH_API int aeth_file_count_structs(const char *path, size_t elem_size, size_t *count);            /* :12-25  */
 AETH_API int aeth_file_read(const char *path, size_t offset_structs, void *dst_host, size_t n, size_t elem_size);  /* BinaryReader::read :46-57 */
 AETH_API int aeth_file_write(const char *path, const void *src_host, size_t n, size_t elem_size, int append);      /* binary_writer + write :83-109 */
-/* raw cf32 file -> FIR -> raw cf32 file through the pipeline above (both files mapped) */
+/* raw cf32 file -> one of the pipeline's ops -> raw file of its output type (cf32, or bit bytes for the demodulating stage)
+ * through the pipeline above (both files mapped; the two paths must not name the same file) */
+AETH_API int aeth_stream_file(aeth_ctx *ctx, const aeth_stream_op *op, const char *in_path, const char *out_path,
+                              size_t chunk_samples, aeth_pipe_stats *stats);
+/* raw cf32 file -> FIR -> raw cf32 file */
 AETH_API int aeth_fir_stream_file(aeth_fir *fir, const char *in_path, const char *out_path, size_t chunk_samples,
                                   aeth_pipe_stats *stats);
 

@@ -151,6 +151,8 @@ extern "C" {
                                 stats: *mut aeth_pipe_stats) -> c_int;
     pub fn aeth_fir_stream_host_util(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,
                                      util: *mut aeth_pipe_util) -> c_int;
+    pub fn aeth_stream_file(ctx: *mut aeth_ctx, op: *const aeth_stream_op, in_path: *const c_char, out_path: *const c_char, chunk: usize,
+                            stats: *mut aeth_pipe_stats) -> c_int;
     pub fn aeth_fir_stream_file(fir: *mut aeth_fir, in_path: *const c_char, out_path: *const c_char, chunk: usize,
                                 stats: *mut aeth_pipe_stats) -> c_int;
     pub fn aeth_file_count_structs(path: *const c_char, elem_size: usize, count: *mut usize) -> c_int;

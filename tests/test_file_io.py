@@ -61,3 +61,36 @@ def test_file_fir_refuses_to_run_in_place(ctx, oracle, tmp_path):
     with pytest.raises(ap.AetherError):
         f.filter_file(str(bad), str(tmp_path / "o.bin"))
     assert not (tmp_path / "o.bin").exists()                              # nothing created for a bad input
+
+
+@pytest.mark.gpu
+def test_file_to_file_through_the_other_pipeline_stages(ctx, tmp_path):
+    """raw cf32 file -> FFT frames / correlate + demod / FFT + interpolate -> raw file (aeth_stream_file): the bytes of
+    the device-resident call on the whole recording; a file that is not whole frames is refused before anything is written"""
+    import aether_primitives_amd as ap
+    from aether_primitives_amd import pipeline, modulation, Scale
+    from helpers import rand_c64
+    N, frames = 1024, 300
+    x = rand_c64(9, N * frames)
+    pin = tmp_path / "rx.cf32"; ap.file.binary_writer(pin).write(x)
+    fft = ap.HipFft(ctx, N, max_batch=frames)
+    sig = ctx.vec(rand_c64(10, N, scale=0.3))
+    # FFT frames
+    st = pipeline.run_file(pipeline.Stage.fft(fft, Scale.SN), pin, tmp_path / "spec.cf32", chunk=N * 64)
+    d = ctx.vec(x); fft.ifwd(d, Scale.SN)
+    assert st["samples"] == x.size and st["chunks"] == 5
+    assert bits_equal(np.fromfile(tmp_path / "spec.cf32", np.complex64), d.to_host())
+    # correlate + demod: a file of bit bytes
+    pipeline.run_file(pipeline.Stage.correlate_demod(fft, sig, 2), pin, tmp_path / "bits.u8")
+    want = modulation.qpsk(ctx).correlate_demod(fft, ctx.vec(x), sig).to_host()
+    assert np.array_equal(np.fromfile(tmp_path / "bits.u8", np.uint8), want)
+    # FFT + interpolate: 1 in, 4 out
+    pipeline.run_file(pipeline.Stage.fft_interpolate(fft, 3, Scale.SN), pin, tmp_path / "up.cf32")
+    o = ctx.empty((N + (N - 1) * 3) * frames); fft.rfft_interpolate(ctx.vec(x), o, 3, Scale.SN)
+    assert bits_equal(np.fromfile(tmp_path / "up.cf32", np.complex64), o.to_host())
+    ragged = tmp_path / "ragged.cf32"; x[: N * 3 + 5].tofile(ragged)
+    with pytest.raises(ap.AetherError):
+        pipeline.run_file(pipeline.Stage.fft(fft, Scale.SN), ragged, tmp_path / "never.cf32")
+    with pytest.raises(ap.AetherError, match="same file"):
+        pipeline.run_file(pipeline.Stage.fft(fft, Scale.SN), pin, pin)
+    assert np.array_equal(np.fromfile(pin, np.complex64).view(np.uint32), x.view(np.uint32))
