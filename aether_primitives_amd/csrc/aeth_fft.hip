@@ -916,12 +916,21 @@ int aeth_fft_exec_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 
     AETH_REQUIRE(n_in == p->len, AETH_E_LEN, AETH_MSG_FFT_LEN);
     AETH_REQUIRE(n_out == p->len, AETH_E_LEN, "Output and FFT must be the same length");
     AETH_REQUIRE(in && out, AETH_E_ARG, "null pointer");
-    rc = ensure_temps(p, 2 * p->len, false); if (rc) return rc;
     aeth::DeviceGuard dev_guard(p->ctx->device);
-    hipStream_t st = aeth::ctx_stream(p->ctx);
     const size_t bytes = p->len * sizeof(float2);
-    AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));   /* tmp[..len] <- input, fft.rs:168 */
     const float s = aeth_scale_factor(kind, p->len, x);
+    if (bytes <= aeth::kZeroCopyMax) {
+        // one frame per call is latency-bound: the kernel reads the frame from and writes the spectrum to pinned host
+        // memory (aeth::HostIO), one launch and one wait instead of H2D + launch + D2H + wait
+        aeth::HostIO io;
+        rc = io.open(p->ctx, bytes, bytes); if (rc) return rc;
+        rc = io.put(0, in, bytes); if (rc) return rc;                               /* tmp[..len] <- input, fft.rs:168 */
+        rc = aeth::fft_run(p, (const float2 *)io.buf[0], (float2 *)io.buf[1], 1, sign, s); if (rc) return rc;
+        return io.get(out, 1, bytes);
+    }
+    rc = ensure_temps(p, 2 * p->len, false); if (rc) return rc;
+    hipStream_t st = aeth::ctx_stream(p->ctx);
+    AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));   /* tmp[..len] <- input, fft.rs:168 */
     rc = aeth::fft_run(p, p->tmp_dev, p->tmp_dev + p->len, 1, sign, s); if (rc) return rc;
     AETH_HIP(hipMemcpyAsync(out, p->tmp_dev + p->len, bytes, hipMemcpyDeviceToHost, st));
     AETH_HIP(hipStreamSynchronize(st));
@@ -940,8 +949,18 @@ int aeth_fft_exec_tmp_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, int si
     aeth::DeviceGuard dev_guard(p->ctx->device);
     hipStream_t st = aeth::ctx_stream(p->ctx);
     const size_t bytes = p->len * sizeof(float2);
-    AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));
     const float s = aeth_scale_factor(kind, p->len, x);
+    if (bytes <= aeth::kZeroCopyMax) {
+        // tmp_host is pinned: the kernel writes the lent half of it directly
+        aeth::HostIO io;
+        rc = io.open(p->ctx, bytes, 0); if (rc) return rc;
+        rc = io.put(0, in, bytes); if (rc) return rc;
+        rc = aeth::fft_run(p, (const float2 *)io.buf[0], p->tmp_host + p->len, 1, sign, s); if (rc) return rc;
+        rc = io.wait(); if (rc) return rc;
+        *view = (const aeth_cf32 *)(p->tmp_host + p->len);
+        return AETH_OK;
+    }
+    AETH_HIP(hipMemcpyAsync(p->tmp_dev, in, bytes, hipMemcpyHostToDevice, st));
     rc = aeth::fft_run(p, p->tmp_dev, p->tmp_dev + p->len, 1, sign, s); if (rc) return rc;
     AETH_HIP(hipMemcpyAsync(p->tmp_host + p->len, p->tmp_dev + p->len, bytes, hipMemcpyDeviceToHost, st));
     AETH_HIP(hipStreamSynchronize(st));

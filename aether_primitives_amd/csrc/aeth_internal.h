@@ -38,6 +38,8 @@ struct aeth_ctx {
     // device scratch of the host-slice flavours, grown on demand
     void *stage[2] = {nullptr, nullptr};
     size_t stage_bytes[2] = {0, 0};
+    // small host-slice calls: two pinned, device-visible bounce buffers (aeth::HostIO)
+    void *bounce[2] = {nullptr, nullptr};
 };
 
 namespace aeth {
@@ -55,6 +57,24 @@ hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintpt
 
 // ensure staging slot `i` holds >= bytes of device memory
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes);
+
+// Buffers of one host-slice call (the literal trait call: host slice in, host slice out, synchronous).
+//   small (every buffer <= kZeroCopyMax): the context's two pinned, device-visible bounce buffers -- memcpy in, the kernel
+//     reads and writes HOST memory over PCIe, one wait, memcpy out: one launch and one completion round trip per call.
+//     Measured (tools/host_latency.hip, 2048 samples): 15.4 us against 31.6 us for pageable H2D -> kernel -> D2H and
+//     19.7 us for pinned async copies around a device-resident kernel; the floor (an empty kernel + wait) is 10.4 us.
+//   large: device staging and the runtime's copy engines, as before (link-rate-bound, not latency-bound).
+constexpr size_t kZeroCopyMax = (size_t)256 << 10;
+struct HostIO {
+    aeth_ctx *ctx;
+    bool pinned;
+    void *buf[2] = {nullptr, nullptr};
+    // bytes0 / bytes1: sizes of the two buffers the call needs (0: unused)
+    int open(aeth_ctx *c, size_t bytes0, size_t bytes1);
+    int put(int slot, const void *src, size_t bytes);          // caller memory -> buffer
+    int get(void *dst, int slot, size_t bytes);                // after the kernels: wait, buffer -> caller memory
+    int wait();                                                // the result stays in the buffer (tfwd / tbwd)
+};
 
 // Tuning knobs: environment integers that are consulted ONLY when the process was started with AETH_TUNING=1; a
 // normal run never reads them.  libaether_hip.so carries the seven that choose between SHIPPED behaviours, all

@@ -524,8 +524,10 @@ int aeth_ctx_trim(aeth_ctx *ctx)
     aeth::DeviceGuard g(ctx->device);
     AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
     aeth::pipe_release(ctx);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) { AETH_HIP(hipFree(ctx->stage[i])); ctx->stage[i] = nullptr; ctx->stage_bytes[i] = 0; }
+        if (ctx->bounce[i]) { AETH_HIP(hipHostFree(ctx->bounce[i])); ctx->bounce[i] = nullptr; }
+    }
     return AETH_OK;
 }
 

@@ -106,6 +106,49 @@ int ctx_stage(aeth_ctx *ctx, int i, size_t bytes)
     return AETH_OK;
 }
 
+int HostIO::open(aeth_ctx *c, size_t bytes0, size_t bytes1)
+{
+    ctx = c;
+    pinned = bytes0 <= kZeroCopyMax && bytes1 <= kZeroCopyMax;
+    const size_t want[2] = {bytes0, bytes1};
+    for (int i = 0; i < 2; i++) {
+        if (!want[i]) continue;
+        if (pinned) {
+            if (!c->bounce[i]) AETH_HIP(hipHostMalloc(&c->bounce[i], kZeroCopyMax, hipHostMallocDefault));    // coherent: the wait below publishes the kernel's stores
+            buf[i] = c->bounce[i];
+        } else {
+            int rc = ctx_stage(c, i, want[i]); if (rc) return rc;
+            buf[i] = c->stage[i];
+        }
+    }
+    return AETH_OK;
+}
+
+int HostIO::put(int slot, const void *src, size_t bytes)
+{
+    if (!bytes) return AETH_OK;
+    if (pinned) { memcpy(buf[slot], src, bytes); return AETH_OK; }
+    AETH_HIP(hipMemcpyAsync(buf[slot], src, bytes, hipMemcpyHostToDevice, ctx_stream(ctx)));
+    return AETH_OK;
+}
+
+int HostIO::wait()
+{
+    AETH_HIP(hipStreamSynchronize(ctx_stream(ctx)));
+    return AETH_OK;
+}
+
+int HostIO::get(void *dst, int slot, size_t bytes)
+{
+    if (pinned) {
+        int rc = wait(); if (rc) return rc;
+        memcpy(dst, buf[slot], bytes);
+        return AETH_OK;
+    }
+    if (bytes) AETH_HIP(hipMemcpyAsync(dst, buf[slot], bytes, hipMemcpyDeviceToHost, ctx_stream(ctx)));
+    return wait();
+}
+
 }  // namespace aeth
 
 using aeth::set_error;
@@ -201,6 +244,7 @@ int aeth_ctx_destroy(aeth_ctx *ctx)
     aeth::pipe_release(ctx);
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+        if (ctx->bounce[i]) (void)hipHostFree(ctx->bounce[i]);
     }
     if (ctx->owns_stream && ctx->stream_main) (void)hipStreamDestroy(ctx->stream_main);
     delete ctx;

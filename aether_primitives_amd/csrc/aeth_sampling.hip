@@ -185,14 +185,13 @@ int aeth_host_interpolate(aeth_ctx *ctx, const aeth_cf32 *src, size_t n_src, aet
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
     const size_t Lo = n_src + (n_src - 1) * nb;
     AETH_REQUIRE(cap >= Lo, AETH_E_LEN, "dst capacity %zu < %zu", cap, Lo);
-    int rc = aeth::ctx_stage(ctx, 0, n_src * sizeof(aeth_cf32)); if (rc) return rc;
-    rc = aeth::ctx_stage(ctx, 1, Lo * sizeof(aeth_cf32)); if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(ctx->stage[0], src, n_src * sizeof(aeth_cf32), hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
-    rc = interpolate_impl(ctx, (const aeth_cf32 *)ctx->stage[0], n_src, 1, (aeth_cf32 *)ctx->stage[1], Lo, nb, compat, n_written);
+    aeth::DeviceGuard dev_guard(ctx->device);
+    aeth::HostIO io;
+    int rc = io.open(ctx, n_src * sizeof(aeth_cf32), Lo * sizeof(aeth_cf32)); if (rc) return rc;
+    rc = io.put(0, src, n_src * sizeof(aeth_cf32)); if (rc) return rc;
+    rc = interpolate_impl(ctx, (const aeth_cf32 *)io.buf[0], n_src, 1, (aeth_cf32 *)io.buf[1], Lo, nb, compat, n_written);
     if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(dst, ctx->stage[1], Lo * sizeof(aeth_cf32), hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
-    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
-    return AETH_OK;
+    return io.get(dst, 1, Lo * sizeof(aeth_cf32));
 }
 
 /* Which build of the reference an entry point matches (src/sampling.rs:32-36 is a debug_assert_eq!):
@@ -254,14 +253,13 @@ static int downsample_host(aeth_ctx *ctx, const void *src, size_t n_src, void *d
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
     int rc = downsample_check(n_src, n_dst, build, step_by); if (rc) return rc;
     AETH_REQUIRE(src && dst, AETH_E_ARG, "null pointer");
-    rc = aeth::ctx_stage(ctx, 0, n_src * elem); if (rc) return rc;
-    rc = aeth::ctx_stage(ctx, 1, n_dst * elem); if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(ctx->stage[0], src, n_src * elem, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
-    rc = downsample_dev(ctx, ctx->stage[0], n_src, ctx->stage[1], n_dst, elem, build, step_by);
+    aeth::DeviceGuard dev_guard(ctx->device);
+    aeth::HostIO io;
+    rc = io.open(ctx, n_src * elem, n_dst * elem); if (rc) return rc;
+    rc = io.put(0, src, n_src * elem); if (rc) return rc;
+    rc = downsample_dev(ctx, io.buf[0], n_src, io.buf[1], n_dst, elem, build, step_by);
     if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(dst, ctx->stage[1], n_dst * elem, hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
-    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
-    return AETH_OK;
+    return io.get(dst, 1, n_dst * elem);
 }
 
 int aeth_downsample(aeth_ctx *ctx, const void *src, size_t n_src, void *dst, size_t n_dst, size_t elem)

@@ -193,23 +193,22 @@ int check_binary(aeth_ctx *ctx, const void *self, size_t n, const void *other, s
     return AETH_OK;
 }
 
-// host-slice flavour: H2D -> kernel -> D2H, synchronous (the literal trait call)
+// host-slice flavour, synchronous (the literal trait call): small slices through the context's pinned bounce buffers
+// (one launch on host memory, one wait), large ones H2D -> kernel -> D2H (aeth::HostIO)
 template <typename F>
 int host_roundtrip(aeth_ctx *ctx, aeth_cf32 *self, size_t n, const aeth_cf32 *other, bool upload_self, F &&run)
 {
     if (n == 0) return AETH_OK;
     const size_t bytes = n * sizeof(aeth_cf32);
     aeth::DeviceGuard dev_guard(ctx->device);
-    int rc = aeth::ctx_stage(ctx, 0, bytes);
+    aeth::HostIO io;
+    int rc = io.open(ctx, bytes, other ? bytes : 0);
     if (rc) return rc;
-    if (other) { rc = aeth::ctx_stage(ctx, 1, bytes); if (rc) return rc; }
-    if (upload_self) AETH_HIP(hipMemcpyAsync(ctx->stage[0], self, bytes, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
-    if (other) AETH_HIP(hipMemcpyAsync(ctx->stage[1], other, bytes, hipMemcpyHostToDevice, aeth::ctx_stream(ctx)));
-    rc = run((aeth_cf32 *)ctx->stage[0], (const aeth_cf32 *)ctx->stage[1]);
+    if (upload_self) { rc = io.put(0, self, bytes); if (rc) return rc; }
+    if (other) { rc = io.put(1, other, bytes); if (rc) return rc; }
+    rc = run((aeth_cf32 *)io.buf[0], (const aeth_cf32 *)io.buf[1]);
     if (rc) return rc;
-    AETH_HIP(hipMemcpyAsync(self, ctx->stage[0], bytes, hipMemcpyDeviceToHost, aeth::ctx_stream(ctx)));
-    AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
-    return AETH_OK;
+    return io.get(self, 0, bytes);
 }
 
 // ---- a chain of element-wise steps in ONE pass over memory ------------------------------------------------------

@@ -27,9 +27,11 @@ outs = [ctx.empty(STREAM) for s in range(ns)]
 ex = fir._lib.aeth_fir_exec
 args = [(fir.h, None, ins[k]._p(), STREAM, outs[k]._p()) for k in range(ns)]
 
-# (label, overlap, first, chained, events)
+# (label, overlap, first, chained, events[, AETH_SYNC_SPIN_US])
 configs = [
     ("2q first16 ch12", True, 16, 12, False),
+    ("2q first16 ch12 spin0", True, 16, 12, False, 0),          # round 4: aeth_ctx_sync blocks on each queue instead of polling both
+    ("2q first16 ch12 spin50", True, 16, 12, False, 50),
     ("2q first16 ch12 ev", True, 16, 12, True),
     ("2q first12 ch12", True, 12, 12, False),
     ("2q first10 ch12", True, 10, 12, False),
@@ -46,8 +48,9 @@ if len(sys.argv) > 3:
 STAMPS = []
 
 
-def region(overlap, first, chained, events, k=None):
+def region(overlap, first, chained, events, spin=2000, k=None):
     k = K if k is None else k
+    os.environ["AETH_SYNC_SPIN_US"] = str(spin)
     os.environ["AETH_FIR_GRID_FIRST"] = str(first)
     os.environ["AETH_FIR_GRID_CHAINED"] = str(chained)
     ctx.set_overlap(overlap)
@@ -103,7 +106,7 @@ print(f"ctx.sync on an idle context: {(time.perf_counter() - t0) / 200 * 1e6:.2f
 print("K sweep (default policy, median of 7 single-shot regions, wall us):")
 rows = []
 for k in (1, 2, 5, 10, 20, 40, 100, 200):
-    v = [region(True, 16, 12, False, k) for _ in range(7)]
+    v = [region(True, 16, 12, False, 2000, k) for _ in range(7)]
     rows.append((k, float(np.median(v)), float(np.min(v))))
 slope = (rows[-1][1] - rows[-2][1]) / (rows[-1][0] - rows[-2][0])
 for k, med, mn in rows:
