@@ -32,6 +32,7 @@ struct aeth_ctx {
     int chain_last = -1;           // lane of the latest FIR launch while nothing else has been enqueued since; else -1
     bool last_chained = false;     // the latest ctx_fir_lane call put its launch beside its predecessor
     uintptr_t last_in[2] = {0, 0}, last_out[2] = {0, 0};   // [lo, hi) byte ranges of that launch
+    unsigned since_sync = 0;       // stream hand-outs (= launches, roughly) since the last aeth_ctx_sync: a short wait blocks, a long one polls
     // host pipeline (aeth_fir_stream_host): stage streams, device slots, events, pinned staging pool, copy threads --
     // created on its first run and kept (aeth_host.h)
     aeth::PipeState *pipe = nullptr;

@@ -50,6 +50,7 @@ hipStream_t ctx_stream(aeth_ctx *ctx)
     }
     ctx->chain_last = -1;
     ctx->last_chained = false;
+    ctx->since_sync++;
     return ctx->stream_main;
 }
 
@@ -86,6 +87,7 @@ hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintpt
         return s;
     }
     if (lane == 1) ctx->aux_pending = true;
+    ctx->since_sync++;
     ctx->last_chained = chained;
     ctx->chain_last = lane;
     ctx->last_in[0] = in_lo; ctx->last_in[1] = in_hi;
@@ -262,9 +264,15 @@ int aeth_ctx_sync(aeth_ctx *ctx)
     hipStream_t waits[2] = {ctx->stream_main, nullptr};
     int nw = 1;
     if (ctx->aux_pending) { waits[nw++] = ctx->stream_aux; }
-    // Short waits are polled: the wake-up latency of a blocking wait is a visible share of a millisecond-long
-    // batch of launches.  After AETH_SYNC_SPIN_US (tuning; default 2000) the blocking wait takes over.
-    const int spin_us = aeth::tuning_int("AETH_SYNC_SPIN_US", 2000);
+    // A batch of launches is waited for by polling: the wake-up latency of a blocking wait is a visible share of a
+    // millisecond-long region (K = 20 fused-FIR launches: 985 us polled, 998 us blocked; tools/k20_lab.py).  After
+    // AETH_SYNC_SPIN_US (tuning; default 2000) the blocking wait takes over.  One or two short launches on one queue
+    // -- the literal "call, then wait" of a device-resident trait call -- are the other way round: the runtime's own
+    // wait spins on the completion signal and returns 6 us sooner than a hipStreamQuery loop (10.4 against 16.5 us for
+    // an empty kernel, tools/host_latency.hip); equal from 70 us on.
+    const bool few = ctx->since_sync <= 2 && !ctx->aux_pending;
+    ctx->since_sync = 0;
+    const int spin_us = few ? 0 : aeth::tuning_int("AETH_SYNC_SPIN_US", 2000);
     bool done[2] = {false, false};
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();

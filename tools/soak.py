@@ -37,7 +37,7 @@ plans, firs = {}, {}
 t0 = last = time.time(); it = 0; worst = -400.0
 while time.time() - t0 < secs:
     it += 1
-    kind = rng.integers(5)
+    kind = rng.integers(8)
     if kind == 0:                                            # FFT, random batch / sign / scale / placement
         n = int(rng.choice(lengths)); batch = int(rng.choice([1, 2, 3, 7, 16, 33, 128]))
         if n * batch > (1 << 22): batch = max(1, (1 << 22) // n)
@@ -88,6 +88,49 @@ while time.time() - t0 < secs:
         compat = bool(rng.integers(2))
         got = m.demod_naive(tx, compat=compat).to_host()
         if not (got == orc.demod_naive(ref, bps, compat=compat)).all(): print(f"demod mismatch bps={bps} nsym={nsym}"); sys.exit(1)
+    elif kind == 5:                                          # round 4: a random chain of links in one pass (aeth_vec_chain), bit-exact
+        n = int(rng.integers(1, 1 << 20)); nl = int(rng.integers(1, 20))
+        ops = [np.complex64(2) + rand_c64(int(rng.integers(1 << 30)), n + 3) for _ in range(3)]
+        dev = [ctx.vec(o) for o in ops]
+        start = rand_c64(int(rng.integers(1 << 30)), n + 3)
+        off = int(rng.integers(0, 3))
+        dv = ctx.vec(start); ch = dv.slice(off, off + n).fused(); want = start[off:off + n].copy()
+        for _ in range(nl):
+            k = int(rng.integers(8)); j = int(rng.integers(3)); oo = int(rng.integers(0, 3))
+            o, do = ops[j][oo:oo + n], dev[j].slice(oo, oo + n)
+            if k == 0: ch.vec_scale(0.9); want = orc.vec_scale(want, 0.9)
+            elif k == 1: ch.vec_mul(do); want = orc.vec_mul(want, o)
+            elif k == 2: ch.vec_div(do); want = orc.vec_div(want, o)
+            elif k == 3: ch.vec_conj(); want = orc.vec_conj(want)
+            elif k == 4: ch.vec_add(do); want = orc.vec_add(want, o)
+            elif k == 5: ch.vec_sub(do); want = orc.vec_sub(want, o)
+            elif k == 6: ch.vec_clone(do); want = o.copy()
+            else: ch.vec_zero(); want = np.zeros(n, np.complex64)
+        ch.run()
+        exp = start.copy(); exp[off:off + n] = want
+        g, e_ = dv.to_host().view(np.float32), exp.view(np.float32)
+        nan = np.isnan(e_)
+        if not ((np.isnan(g) == nan).all() and (g.view(np.uint32)[~nan] == e_.view(np.uint32)[~nan]).all()): print(f"chain mismatch n={n} links={nl} off={off}"); sys.exit(1)
+    elif kind in (6, 7):                                     # round 4: a host stream through a random pipeline stage, bit-exact against the device call
+        from aether_primitives_amd import pipeline, modulation
+        N = int(rng.choice([1024, 2048, 4096])); frames = int(rng.integers(1, 400))
+        if N not in plans: plans[N] = HipFft(ctx, N, max_batch=128)
+        f = plans[N]; x = rand_c64(int(rng.integers(1 << 30)), N * frames)
+        sigh = rand_c64(int(rng.integers(1 << 30)), N, scale=0.3); sig = ctx.vec(sigh)
+        chunk = int(rng.choice([0, N, N * 3, N * 64]))
+        which = int(rng.integers(4))
+        if which == 0:
+            y, _ = pipeline.run(pipeline.Stage.fft(f, Scale.SN), x, chunk=chunk); d = ctx.vec(x); f.ifwd(d, Scale.SN); ok = bits_equal(y, d.to_host())
+        elif which == 1:
+            y, _ = pipeline.run(pipeline.Stage.mul_chain(f, sig), x, chunk=chunk); d = ctx.vec(x); f.mul_chain(d, sig); ok = bits_equal(y, d.to_host())
+        elif which == 2:
+            bps = int(rng.choice([1, 2])); m = modulation.qpsk(ctx) if bps == 2 else modulation.bpsk(ctx)
+            y, _ = pipeline.run(pipeline.Stage.correlate_demod(f, sig, bps), x, chunk=chunk); ok = np.array_equal(y, m.correlate_demod(f, ctx.vec(x), sig).to_host())
+        else:
+            nb = int(rng.choice([1, 3, 9])); y, _ = pipeline.run(pipeline.Stage.fft_interpolate(f, nb, Scale.N), x, chunk=chunk)
+            o = ctx.empty((N + (N - 1) * nb) * frames); f.rfft_interpolate(ctx.vec(x), o, nb, Scale.N); ok = bits_equal(y, o.to_host())
+        if not ok: print(f"pipeline mismatch stage={which} N={N} frames={frames} chunk={chunk}"); sys.exit(1)
+        if it % 50 == 0: ctx.trim()
     else:                                                    # element-wise chain, bit-exact
         n = int(rng.integers(1, 1 << 20))
         a, b = rand_c64(int(rng.integers(1 << 30)), n), rand_c64(int(rng.integers(1 << 30)), n) + np.complex64(2)
