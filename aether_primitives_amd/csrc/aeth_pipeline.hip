@@ -420,9 +420,21 @@ int op_fir(aeth_fir *f, StageOp &op)
 int make_op(aeth_ctx *ctx, const aeth_stream_op *d, StageOp &op)
 {
     AETH_REQUIRE(ctx && d, AETH_E_ARG, "null argument");
-    if (d->kind == AETH_STREAM_FIR) {
+    if (d->kind == AETH_STREAM_FIR || d->kind == AETH_STREAM_FIR_DECIM) {
         int rc = op_fir(d->fir, op); if (rc) return rc;
         AETH_REQUIRE(op.ctx == ctx, AETH_E_ARG, "the filter belongs to another context");
+        if (d->kind == AETH_STREAM_FIR_DECIM) {
+            // the filter followed by sampling::downsample (sampling.rs:28-42) in the kernel's store: out[i] = y[i * dec].
+            // Chunks are whole hops, so with dec | hop every chunk starts on a kept sample and keeps hop / dec per hop.
+            aeth_fir *f = d->fir;
+            const size_t dec = d->n_between;
+            AETH_REQUIRE(dec >= 1 && f->hop % dec == 0, AETH_E_ARG, "decimation %zu must divide the filter's hop (%zu)", dec, f->hop);
+            op.out_per_align = f->hop / dec;
+            op.run = [f, dec](hipStream_t, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out) {
+                if (cnt % dec != 0) return aeth::set_error(AETH_E_ARG, AETH_MSG_DECIM);          /* sampling.rs:32-36 */
+                return aeth_fir_exec_decim(f, have_hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout, cnt_out);
+            };
+        }
         return AETH_OK;
     }
     aeth_fft *p = d->fft;
@@ -471,7 +483,9 @@ int stream_any(aeth_ctx *ctx, const aeth_stream_op *d, const void *in, size_t n_
 {
     StageOp op;
     int rc = make_op(ctx, d, op); if (rc) return rc;
-    if (d->kind != AETH_STREAM_FIR)
+    if (d->kind == AETH_STREAM_FIR_DECIM)
+        AETH_REQUIRE(n_in % d->n_between == 0, AETH_E_ARG, AETH_MSG_DECIM);           /* sampling.rs:32-36 */
+    else if (d->kind != AETH_STREAM_FIR)
         AETH_REQUIRE(n_in % op.align == 0, AETH_E_LEN, AETH_MSG_FFT_LEN);             /* fft.rs:163-167: whole frames only */
     return stream_host(op, nullptr, in, n_in, out, n_out, chunk, stats, util);
 }

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import check
 from .fft import Scale, SIGN_REF_FWD
 
-FIR, FFT, FFT_MUL_IFFT, FFT_MUL_IFFT_DEMOD, FFT_INTERPOLATE = range(5)
+FIR, FFT, FFT_MUL_IFFT, FFT_MUL_IFFT_DEMOD, FFT_INTERPOLATE, FIR_DECIM = range(6)
 
 
 class _Op(C.Structure):
@@ -40,6 +40,11 @@ class Stage:
     @staticmethod
     def fir(f):
         return Stage(f.ctx, _Op(kind=FIR, fir=f.h), np.complex64, (f,))
+
+    @staticmethod
+    def fir_decim(f, dec):
+        """the filter, then sampling::downsample (sampling.rs:28-42) in its store: n in, n / dec out"""
+        return Stage(f.ctx, _Op(kind=FIR_DECIM, fir=f.h, n_between=dec), np.complex64, (f,))
 
     @staticmethod
     def fft(plan, scale=Scale.NONE, sign=SIGN_REF_FWD):

@@ -385,6 +385,7 @@ struct Stage {
     }
 };
 inline Stage stage_fir(const Fir &f) { Stage s; s.op.kind = AETH_STREAM_FIR; s.op.fir = f.get(); return s; }
+inline Stage stage_fir_decim(const Fir &f, size_t dec) { Stage s; s.op.kind = AETH_STREAM_FIR_DECIM; s.op.fir = f.get(); s.op.n_between = dec; return s; }
 inline Stage stage_fft(const HipFft &f, Scale sc, int sign = HipFft::kFwdSign)
 {
     Stage s; s.op.kind = AETH_STREAM_FFT; s.op.fft = f.get(); s.op.sign = sign; s.op.scale_kind_fwd = sc.kind; s.op.x_fwd = sc.x; return s;

@@ -30,6 +30,7 @@ pub const AETH_STREAM_FFT: c_int = 1;
 pub const AETH_STREAM_FFT_MUL_IFFT: c_int = 2;
 pub const AETH_STREAM_FFT_MUL_IFFT_DEMOD: c_int = 3;
 pub const AETH_STREAM_FFT_INTERPOLATE: c_int = 4;
+pub const AETH_STREAM_FIR_DECIM: c_int = 5;
 /// aeth_pipe_util: the same plus the seconds each stage (upload, kernel, download) was active -- the per-stage
 /// utilisation report of src/pipeline.rs:89-114
 #[repr(C)]

@@ -90,6 +90,22 @@ def test_fir_through_the_generic_entry_point(ctx):
     assert bits_equal(y, f.filter(x)) and bits_equal(y, f.filter_stream(x)[0])
 
 
+@pytest.mark.parametrize("dec,blocks,chunk", [(4, 70, 1984 * 16), (31, 12, 0), (64, 200, 1984 * 33)])
+def test_fir_with_decimating_store_as_a_stage(ctx, dec, blocks, chunk):
+    """the filter followed by sampling::downsample in the kernel's store (aeth_fir_exec_decim) over a host stream:
+    8 B in, 8 / dec B out per sample; the decimation has to divide the hop so that every chunk starts on a kept sample"""
+    f = Fir(ctx, rand_c64(1, 64, scale=0.2), 2048)
+    n = 1984 * blocks + dec * 5                              # a ragged last chunk that is still a multiple of dec
+    x = rand_c64(dec + blocks, n)
+    y, st = pipeline.run(pipeline.Stage.fir_decim(f, dec), x, chunk=chunk)
+    want = f.filter_decim(ctx.vec(x), dec).to_host()
+    assert y.size == n // dec and bits_equal(y, want) and bits_equal(y, f.filter(x)[::dec])
+    with pytest.raises(ap.AetherError, match="divide"):
+        pipeline.run(pipeline.Stage.fir_decim(f, 3), x[: 1984 * 3])          # 3 does not divide 1984
+    with pytest.raises(ap.AetherError, match="Only even decimations"):
+        pipeline.run(pipeline.Stage.fir_decim(f, dec), x[: n - 1])
+
+
 def test_stream_from_and_into_pool_elements(ctx, plan, sig):
     """pinned on both sides: no host stage (stats: pinned == 3); the demodulator's byte output lands in a pool element"""
     frames = 64

@@ -9,7 +9,8 @@ under different orders / queue layouts of the same two fused calls per channel, 
    two-ctx+lane  two contexts, each phased with its lane on
 Every layout's decided bits are compared with the first layout's.
    python3 tools/c4_lab.py [rounds=7] [steps=20]"""
-import sys, time, json
+import os, sys, time, json
+os.environ.setdefault("AETH_TUNING", "1")          # the grid sweep at the end uses AETH_FIR_GRID_FIRST
 import numpy as np
 sys.path.insert(0, ".")
 import aether_primitives_amd as ap
@@ -116,4 +117,21 @@ for name, _ in layouts:
     v = sorted(t[name]); med = v[len(v) // 2]
     rows[name] = {"ms_per_step": round(med * 1e3, 4), "GS_per_s": round(nch * n / med / 1e9, 1), "frac_of_20B_line": round(nch * n * 20 / med / 8e12, 3)}
     print(f"  {name:16s} {med * 1e3:8.3f} ms  {nch * n / med / 1e9:7.1f} GS/s   {nch * n * 20 / med / 8e12:.3f} of the 20 B/sample line")
+# Can the two kernels SHARE compute units?  The correlator holds 248 VGPRs per lane: two of its waves fill a SIMD's
+# register file and no generator wave (40 VGPRs) fits beside them.  With fewer correlator workgroups resident (a
+# fraction of the full grid, AETH_FIR_GRID_FIRST sixteenths; needs the overlap switch on, the lane itself never
+# forms here: a modulate call sits between two correlate calls) some SIMDs keep room for generator waves.
+print("== two contexts, interleaved, correlator grid in sixteenths of the resident grid ==")
+for g in (16, 14, 12, 10, 8, 6):
+    os.environ["AETH_FIR_GRID_FIRST"] = str(g)
+    ts = []
+    for r in range(rounds):
+        for _ in range(3): run_two("interleaved", True)
+        sync_all(); t0 = time.perf_counter()
+        for _ in range(steps): run_two("interleaved", True)
+        sync_all(); ts.append((time.perf_counter() - t0) / steps)
+    med = sorted(ts)[len(ts) // 2]
+    rows[f"two-ctx grid {g}/16"] = {"ms_per_step": round(med * 1e3, 4), "GS_per_s": round(nch * n / med / 1e9, 1)}
+    print(f"  grid {g:2d}/16        {med * 1e3:8.3f} ms  {nch * n / med / 1e9:7.1f} GS/s")
+os.environ["AETH_FIR_GRID_FIRST"] = "16"
 json.dump(rows, open("gpurun_out/c4_lab.json", "w"), indent=1)
