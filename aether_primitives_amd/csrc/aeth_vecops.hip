@@ -110,17 +110,26 @@ int launch_ew(aeth_ctx *ctx, aeth_cf32 *self, const aeth_cf32 *other, size_t n, 
 // ---- frames[f][j] *= sig[j]: vec_mul with one operand shared by every frame ------------------------------
 // (the middle of `c.vec_rfft(fft, s).vec_mul(&sig).vec_rifft(fft, s)` over chunks_mut(fft_len), benches.rs:410-416
 // and util/plot.rs:59-61).  One launch for any number of frames: grid.x covers a frame, grid.y walks the frames.
-template <bool NT>
-__global__ __launch_bounds__(kBlock) void mul_frames_kernel(float2 *__restrict__ frames, const float2 *__restrict__ sig,
-                                                            size_t frame_len, size_t batch)
+// One lane per sample (or pair of samples) of the WHOLE batch, the position inside the frame by a multiply-high
+// division: full wavefronts whatever the frame length (round 1's form gave every frame its own row of workgroups --
+// a 100-sample frame kept 100 of 256 lanes busy: 4.5 TB/s; this form: one 8- or 16-byte access per lane like the
+// other element-wise kernels).
+template <typename V, bool NT>
+__global__ __launch_bounds__(kBlock) void mul_frames_kernel(V *__restrict__ frames, const float2 *__restrict__ sig,
+                                                            aeth::FastDiv flen, size_t items)
 {
-    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= frame_len) return;
-    const float2 b = sig[j];                                    // re-read by every frame: stays in cache
-    for (size_t f = blockIdx.y; f < batch; f += gridDim.y) {
-        float2 *p = frames + f * frame_len + j;
-        aeth::nt_store<NT>(p, apply2<OP_MUL>(aeth::nt_load<NT>(p), b, 0.f));
-    }
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;             // item = sizeof(V) / 8 samples
+    if (i >= items) return;
+    constexpr unsigned S = sizeof(V) / sizeof(float2);
+    // sample index modulo the frame length; 32-bit arithmetic on a per-chunk basis (the host side launches chunks of
+    // at most 2^31 samples that start on a frame boundary)
+    const unsigned s0 = (unsigned)i * S;
+    const unsigned j = s0 - aeth::fdiv(s0, flen) * flen.d;
+    V a = aeth::nt_load<NT>(frames + i);
+    if constexpr (S == 2) {
+        const float4 b = *reinterpret_cast<const float4 *>(sig + j);      // frame length even, j even: 16-byte aligned, never wraps
+        aeth::nt_store<NT>(frames + i, apply4<OP_MUL>(a, b, 0.f));
+    } else aeth::nt_store<NT>(frames + i, apply2<OP_MUL>(a, sig[j], 0.f));
 }
 
 int launch_mul_frames(aeth_ctx *ctx, aeth_cf32 *frames, size_t frame_len, size_t batch, const aeth_cf32 *sig)
@@ -128,12 +137,26 @@ int launch_mul_frames(aeth_ctx *ctx, aeth_cf32 *frames, size_t frame_len, size_t
     if (frame_len == 0 || batch == 0) return AETH_OK;
     aeth::DeviceGuard dev_guard(ctx->device);
     const bool nt = aeth::streams_past_cache(2 * batch * frame_len * sizeof(float2));
-    const size_t gx = (frame_len + kBlock - 1) / kBlock;
-    // enough workgroups to fill the chip, at most 65535 rows of them
-    size_t gy = batch < 65535 ? batch : 65535;
-    auto k = nt ? mul_frames_kernel<true> : mul_frames_kernel<false>;
-    hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, aeth::ctx_stream(ctx),
-                       reinterpret_cast<float2 *>(frames), reinterpret_cast<const float2 *>(sig), frame_len, batch);
+    float2 *f = reinterpret_cast<float2 *>(frames);
+    const float2 *sg = reinterpret_cast<const float2 *>(sig);
+    const bool wide = frame_len % 2 == 0 && aeth::aligned16(frames) && aeth::aligned16(sig);
+    const aeth::FastDiv fd = aeth::make_fastdiv((uint32_t)frame_len);
+    AETH_REQUIRE(frame_len < ((size_t)1 << 31), AETH_E_UNSUPPORTED, "frame length %zu", frame_len);
+    // chunks of whole frames, under 2^31 samples each
+    const size_t per = (((size_t)1 << 31) - 1) / frame_len;
+    for (size_t f0 = 0; f0 < batch; f0 += per) {
+        const size_t nf = batch - f0 < per ? batch - f0 : per;
+        const size_t samples = nf * frame_len, items = wide ? samples / 2 : samples;
+        const dim3 grid(grid_for(ctx, items));
+        float2 *base = f + f0 * frame_len;
+        if (wide) {
+            auto k = nt ? mul_frames_kernel<float4, true> : mul_frames_kernel<float4, false>;
+            hipLaunchKernelGGL(k, grid, dim3(kBlock), 0, aeth::ctx_stream(ctx), reinterpret_cast<float4 *>(base), sg, fd, items);
+        } else {
+            auto k = nt ? mul_frames_kernel<float2, true> : mul_frames_kernel<float2, false>;
+            hipLaunchKernelGGL(k, grid, dim3(kBlock), 0, aeth::ctx_stream(ctx), base, sg, fd, items);
+        }
+    }
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

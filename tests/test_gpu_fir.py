@@ -208,6 +208,10 @@ def test_vec_mul_frames_bit_exact(ctx, oracle, n, batch):
     assert bits_equal(got, tiled)
     with pytest.raises(AssertionError, match="Vectors must have same length"):
         ctx.vec(frames).vec_mul_frames(ctx.vec(np.concatenate([sig, sig[:1]])), frame_len=n)
+    # frames and signal on odd 8-byte slots (no 16-byte accesses), even and odd frame lengths alike
+    pad = ctx.vec(np.concatenate([frames[:1], frames])); spad = ctx.vec(np.concatenate([sig[:1], sig]))
+    pad.slice(1, 1 + n * batch).vec_mul_frames(spad.slice(1, 1 + n), frame_len=n)
+    assert bits_equal(pad.to_host()[1:], tiled) and bits_equal(pad.to_host()[:1], frames[:1])
 
 
 @pytest.mark.parametrize("n,chunk", [(1000, 1984), (1984 * 7 + 5, 1984 * 2), (3_000_000, 1 << 20), (1 << 23, 0)])
