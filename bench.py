@@ -226,12 +226,23 @@ def side_workload(args):
     if args.workload == "c2":
         scaling = "weak"
         n = 1 << 20                                             # 512 frames: 8 MiB, cache-resident by definition
-        f = ap.HipFft(ctx, N, max_batch=n // N)
-        bufs = [(ctx.vec(synth_stream(815 + i, n)), ctx.empty(n)) for i in range(4)]
+        # The two launches of a step are 3 us of traffic each: launch-latency-bound.  Steps work on independent buffer
+        # pairs, so they are dealt alternately to two contexts = two HIP queues of this GPU (as for C4): the launch
+        # latency of one step runs beside the kernels of the other.  --c2-one-queue: round 3's single context.
+        nq = 1 if args.c2_one_queue else 2
+        ctxs = [ctx] + [ap.Context(ranks.local_rank) for _ in range(nq - 1)]
+        plans = [ap.HipFft(c, N, max_batch=n // N) for c in ctxs]
+        bufs = [(ctxs[i % nq].vec(synth_stream(815 + i, n)), ctxs[i % nq].empty(n)) for i in range(4)]
         def step(i):
-            a, b = bufs[i % 4]; f.fwd(a, b, Scale.SN); f.ifwd(a, Scale.SN)      # benches.rs:305-306,352-353
+            a, b = bufs[i % 4]; f = plans[(i % 4) % nq]
+            f.fwd(a, b, Scale.SN); f.ifwd(a, Scale.SN)          # benches.rs:305-306,352-353
+
+        class _All:
+            def sync(self_):
+                for c in ctxs: c.sync()
+        ctx = _All()
         job_samples = 2 * n * args.gpus
-        name, bytes_ = "C2: FFT-2048 fwd (copy) + ifwd (in place) on a 1 Mi-sample stream per GPU", 32 * n
+        name, bytes_ = f"C2: FFT-2048 fwd (copy) + ifwd (in place) on a 1 Mi-sample stream per GPU, {nq} queue(s) per GPU", 32 * n
         shard = "one stream per rank"
     elif args.workload == "c5":
         total_frames, nb = 512, 9
@@ -452,6 +463,7 @@ def main():
                      help="skip the extra leg that repeats the timed steps on one queue (per-launch kernel time)")
     ap_.add_argument("--as-rank", type=int, default=None, help="--workload c4|c5 on ONE GPU: run this rank's share of an --of W rank job (modelled scaling)")
     ap_.add_argument("--of", type=int, default=1)
+    ap_.add_argument("--c2-one-queue", action="store_true", help="--workload c2 on one context / one HIP queue per GPU (round 3's layout)")
     ap_.add_argument("--c4-one-queue", action="store_true", help="--workload c4 on one context / one HIP queue per GPU (round 3's layout)")
     ap_.add_argument("--c4-unfused", action="store_true", help="--workload c4 as four calls per channel (modulate, apply, mul_chain, demod)")
     ap_.add_argument("--c5-unfused", action="store_true", help="--workload c5 as two calls (fft, then interpolate)")
