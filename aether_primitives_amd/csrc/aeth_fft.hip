@@ -909,6 +909,10 @@ int aeth_fft_exec_tmp(aeth_fft *p, const aeth_cf32 *in, size_t n_in, size_t batc
     return AETH_OK;
 }
 
+// one frame per call on host memory: frames up to 8192 points (one launch, coalesced rows) read and write the pinned bounce
+// buffers directly; longer ones (several launches, strided first pass) go through device memory as before
+static constexpr size_t kFftZeroCopyMax = (size_t)64 << 10;
+
 int aeth_fft_exec_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 *out, size_t n_out, int sign,
                        int kind, float x)
 {
@@ -919,7 +923,7 @@ int aeth_fft_exec_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, aeth_cf32 
     aeth::DeviceGuard dev_guard(p->ctx->device);
     const size_t bytes = p->len * sizeof(float2);
     const float s = aeth_scale_factor(kind, p->len, x);
-    if (bytes <= aeth::kZeroCopyMax) {
+    if (bytes <= kFftZeroCopyMax) {
         // one frame per call is latency-bound: the kernel reads the frame from and writes the spectrum to pinned host
         // memory (aeth::HostIO), one launch and one wait instead of H2D + launch + D2H + wait
         aeth::HostIO io;
@@ -950,7 +954,7 @@ int aeth_fft_exec_tmp_host(aeth_fft *p, const aeth_cf32 *in, size_t n_in, int si
     hipStream_t st = aeth::ctx_stream(p->ctx);
     const size_t bytes = p->len * sizeof(float2);
     const float s = aeth_scale_factor(kind, p->len, x);
-    if (bytes <= aeth::kZeroCopyMax) {
+    if (bytes <= kFftZeroCopyMax) {
         // tmp_host is pinned: the kernel writes the lent half of it directly
         aeth::HostIO io;
         rc = io.open(p->ctx, bytes, 0); if (rc) return rc;
