@@ -4,11 +4,13 @@ A/B in one process, 512 frames (one GPU's job) and 64 frames (an 8-GPU shard):
    default            two launches over the whole batch (step A, step B)
    groups g           the same, group by group through a g-MiB work buffer (AETH_4S_GROUP_MIB)
    parts              frame halves on two HIP streams (AETH_4S_PARTS=2): one half's step B beside the other's step A
+                      -- round 3's shape; its code left the library in round 4 (numbers: profiles/r03_c5.json), the knob is a no-op now
    parts + groups g   g-MiB groups alternating between the two streams
 Every shape's output is compared bit for bit with the default's.  One shape only (for rocprofv3 --pmc runs):
    AETH_TUNING=1 python3 tools/c5_shapes.py --only "parts+groups 64" --batch 512 --launches 20"""
 import argparse, os, sys, time
 os.environ.setdefault("AETH_TUNING", "1")
+os.environ.setdefault('AETH_LAB_LIB', '1')   # these knobs exist only in the lab build: make -C aether_primitives_amd/csrc LAB=1
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import aether_primitives_amd as ap

@@ -5,6 +5,7 @@ pass (AETH_MIXED_BIGR=0), the same kernel with its register butterflies for 11..
 against numpy's f64 transform."""
 import os, sys, statistics
 os.environ['AETH_TUNING'] = '1'
+os.environ.setdefault('AETH_LAB_LIB', '1')   # these knobs exist only in the lab build: make -C aether_primitives_amd/csrc LAB=1
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import aether_primitives_amd as ap

@@ -5,6 +5,7 @@ build's (the knobs may only change scheduling, never arithmetic -- AETH_4S_NOTW 
 usage: tune_4step.py [batch] [N] -- "K=V K=V" "K=V" ...   (each quoted string = one variant)"""
 import os, sys, statistics
 os.environ.setdefault('AETH_TUNING', '1')   # enables the library's AETH_* tuning knobs
+os.environ.setdefault('AETH_LAB_LIB', '1')   # these knobs exist only in the lab build: make -C aether_primitives_amd/csrc LAB=1
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import aether_primitives_amd as ap

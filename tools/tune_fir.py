@@ -22,7 +22,7 @@ ins = [ctx.vec(synth_stream(815 + i, n)) for i in range(ns)]
 outs = [ctx.empty(n) for _ in range(ns)]
 e0, e1 = ctx.event(), ctx.event()
 res = {v: [] for v in variants}
-KEYS = ["AETH_FIR_DBG", "AETH_FIR_GRID", "AETH_FIR_VARIANT"]
+KEYS = ["AETH_FIR_GRID_FIRST", "AETH_FIR_GRID_CHAINED", "AETH_FIR_SPREAD", "AETH_NT"]     # the knobs the library still reads (aether_hip.h)
 for rnd in range(6):
     for v in variants:
         for k in KEYS: os.environ.pop(k, None)
