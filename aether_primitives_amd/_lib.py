@@ -101,6 +101,8 @@ PROTOTYPES = {
     "aeth_vec_chain": (i32, [vp, vp, sz, vp, sz]),
     "aeth_stream_out_count": (sz, [vp, vp, sz]),
     "aeth_stream_host": (i32, [vp, vp, vp, sz, vp, sz, sz, vp]),
+    "aeth_stream_chain_out_count": (sz, [vp, vp, sz, sz]),
+    "aeth_stream_host_chain": (i32, [vp, vp, sz, vp, sz, vp, sz, sz, vp, vp]),
     "aeth_stream_host_util": (i32, [vp, vp, vp, sz, vp, sz, sz, vp]),
     "aeth_ctx_trim": (i32, [vp]),
     "aeth_test_fail_staging_after": (None, [i32]),

@@ -30,6 +30,8 @@ struct PipeState {
     float2 *din[kPipeSlots] = {nullptr, nullptr, nullptr};          // device: [history | chunk]
     float2 *dout[kPipeSlots] = {nullptr, nullptr, nullptr};
     size_t din_bytes = 0, dout_bytes = 0;
+    void *mid[kPipeSlots][2] = {};                                   // scratch pair per slot (a chain of ops as the compute stage)
+    size_t mid_bytes = 0;
     hipEvent_t up[kPipeSlots] = {}, ran[kPipeSlots] = {}, down[kPipeSlots] = {};
     aeth_pool *pool[2] = {nullptr, nullptr};                         // pinned staging elements per side, in | out (src/pool.rs)
     CopyTeam *team = nullptr;

@@ -31,6 +31,7 @@
 #include <functional>
 #include <memory>
 #include <new>
+#include <vector>
 
 namespace aeth {
 
@@ -54,6 +55,7 @@ void pipe_release(aeth_ctx *ctx)
     for (int s = 0; s < kPipeSlots; s++) {
         if (p->din[s]) (void)hipFree(p->din[s]);
         if (p->dout[s]) (void)hipFree(p->dout[s]);
+        for (int k = 0; k < 2; k++) if (p->mid[s][k]) (void)hipFree(p->mid[s][k]);
         if (p->up[s]) (void)hipEventDestroy(p->up[s]);
         if (p->ran[s]) (void)hipEventDestroy(p->ran[s]);
         if (p->down[s]) (void)hipEventDestroy(p->down[s]);
@@ -84,9 +86,12 @@ struct StageOp {
     size_t align = 1;                      // chunk granularity in input elements (FIR: hop; frame ops: the frame length)
     size_t out_per_align = 1;              // output elements per `align` input elements (out_count is linear in the input)
     bool inplace = false;                  // the op leaves its result in the input slot (aeth_fft_mul_ifft)
+    size_t mid_per_align = 0;              // bytes of device scratch per `align` input elements, twice (a chain of ops: the
+                                           // intermediates ping-pong between two scratch buffers of the slot)
     // din_chunk: first input element of the chunk in the device slot (hist elements of context in front of it when
-    // have_hist); runs on `s` and must not wait for the host
-    std::function<int(hipStream_t s, const void *din_hist, void *din_chunk, bool have_hist, size_t cnt, void *dout, size_t cnt_out)> run;
+    // have_hist); runs on `s` and must not wait for the host; mid0 / mid1: the slot's scratch pair (chains only)
+    std::function<int(hipStream_t s, const void *din_hist, void *din_chunk, bool have_hist, size_t cnt, void *dout, size_t cnt_out,
+                      void *mid0, void *mid1)> run;
     size_t out_count(size_t cnt) const { return cnt / align * out_per_align + (cnt % align) * out_per_align / align; }
 };
 
@@ -100,7 +105,7 @@ struct StreamSwap {
 };
 
 // streams, events, device slots of `din_bytes` / `dout_bytes`, grown (never shrunk; aeth_ctx_trim releases) between calls
-int pipe_prepare(aeth_ctx *ctx, size_t din_bytes, size_t dout_bytes, int nslots)
+int pipe_prepare(aeth_ctx *ctx, size_t din_bytes, size_t dout_bytes, int nslots, size_t mid_bytes = 0)
 {
     if (!ctx->pipe) {
         ctx->pipe = new (std::nothrow) PipeState();
@@ -130,6 +135,15 @@ int pipe_prepare(aeth_ctx *ctx, size_t din_bytes, size_t dout_bytes, int nslots)
         if (!p->din[s]) AETH_HIP(hipMalloc((void **)&p->din[s], p->din_bytes));
         if (!p->dout[s]) AETH_HIP(hipMalloc((void **)&p->dout[s], p->dout_bytes));
     }
+    if (mid_bytes > p->mid_bytes) {                  // scratch pair per slot of a chain of ops
+        for (int i = 0; i < 3; i++) AETH_HIP(hipStreamSynchronize(p->stream[i]));
+        for (int s = 0; s < kPipeSlots; s++)
+            for (int k = 0; k < 2; k++) if (p->mid[s][k]) { AETH_HIP(hipFree(p->mid[s][k])); p->mid[s][k] = nullptr; }
+        p->mid_bytes = mid_bytes;
+    }
+    if (mid_bytes)
+        for (int s = 0; s < nslots; s++)
+            for (int k = 0; k < 2; k++) if (!p->mid[s][k]) AETH_HIP(hipMalloc((void **)&p->mid[s][k], p->mid_bytes));
     if (!p->team) {
         // three eighths of the cores this process may USE, 2 .. 12 (tuning: AETH_PIPE_THREADS).  Created BEFORE any staging
         // element is taken, so that no error path between the two leaves elements checked out.
@@ -238,7 +252,7 @@ int stream_host(const StageOp &op, const void *hist, const void *in_, size_t n, 
     // (AETH_PIPE_MIXED=1 under AETH_TUNING=1 keeps the direct download; include/aether_hip.h, "Tuning knobs").
     if (stage_in && !stage_out && aeth::tuning_int("AETH_PIPE_MIXED", 0) == 0) stage_out = true;
 
-    int rc = pipe_prepare(ctx, in_slot_bytes, op.inplace ? 16 : out_slot_bytes, nslots);
+    int rc = pipe_prepare(ctx, in_slot_bytes, op.inplace ? 16 : out_slot_bytes, nslots, op.mid_per_align * cu);
     if (rc) return rc;
     PipeState *ps = ctx->pipe;
     void *pin_in[kPipeSlots] = {}, *pin_out[kPipeSlots] = {};
@@ -333,7 +347,7 @@ int stream_host(const StageOp &op, const void *hist, const void *in_, size_t n, 
                 if (!ok(hipStreamWaitEvent(s_run, ps->up[s], 0), "hipStreamWaitEvent")) break;
                 if (used && !ok(hipStreamWaitEvent(s_run, ps->down[s], 0), "hipStreamWaitEvent")) break;
                 mark(k, 1, 0, s_run);
-                rc = op.run(s_run, din, din + nh * IU, (o0 || hist) && nh, cnt, dout, cnt_out);
+                rc = op.run(s_run, din, din + nh * IU, (o0 || hist) && nh, cnt, dout, cnt_out, ps->mid[s][0], ps->mid[s][1]);
                 if (rc) break;
                 mark(k, 1, 1, s_run);
                 if (!ok(hipEventRecord(ps->ran[s], s_run), "hipEventRecord")) break;
@@ -411,7 +425,7 @@ int op_fir(aeth_fir *f, StageOp &op)
 {
     AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
     op.ctx = f->ctx; op.hist = f->ntaps - 1; op.align = f->hop; op.out_per_align = f->hop;
-    op.run = [f](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t) {
+    op.run = [f](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t, void *, void *) {
         return aeth::fir_exec_on(f, s, have_hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout);
     };
     return AETH_OK;
@@ -430,7 +444,7 @@ int make_op(aeth_ctx *ctx, const aeth_stream_op *d, StageOp &op)
             const size_t dec = d->n_between;
             AETH_REQUIRE(dec >= 1 && f->hop % dec == 0, AETH_E_ARG, "decimation %zu must divide the filter's hop (%zu)", dec, f->hop);
             op.out_per_align = f->hop / dec;
-            op.run = [f, dec](hipStream_t, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out) {
+            op.run = [f, dec](hipStream_t, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out, void *, void *) {
                 if (cnt % dec != 0) return aeth::set_error(AETH_E_ARG, AETH_MSG_DECIM);          /* sampling.rs:32-36 */
                 return aeth_fir_exec_decim(f, have_hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout, cnt_out);
             };
@@ -445,27 +459,27 @@ int make_op(aeth_ctx *ctx, const aeth_stream_op *d, StageOp &op)
     const aeth_stream_op c = *d;                     // by value: the descriptor need not outlive the call, but does anyway
     switch (d->kind) {
     case AETH_STREAM_FFT:                            // Fft::fwd / bwd over chunks_mut(fft_len) (src/util/plot.rs:59-61)
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t, void *, void *) {
             return aeth_fft_exec(p, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout, cnt / N, c.sign, c.scale_kind_fwd, c.x_fwd);
         };
         return AETH_OK;
     case AETH_STREAM_FFT_MUL_IFFT:                   // benches/benches.rs:410-416, in place
         op.inplace = true;
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *, size_t) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *, size_t, void *, void *) {
             return aeth_fft_mul_ifft(p, (aeth_cf32 *)dc, cnt, cnt / N, c.sig_dev, c.n_sig, c.scale_kind_fwd, c.x_fwd, c.scale_kind_bwd, c.x_bwd);
         };
         return AETH_OK;
     case AETH_STREAM_FFT_MUL_IFFT_DEMOD:             // ... then Modulation::demod_naive (examples/modem.rs:28-31)
         AETH_REQUIRE(c.bits_per_symbol == 1 || c.bits_per_symbol == 2, AETH_E_UNSUPPORTED, "bits_per_symbol %d: BPSK (1) or QPSK (2)", c.bits_per_symbol);
         op.out_unit = 1; op.out_per_align = N * (size_t)c.bits_per_symbol;
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out, void *, void *) {
             return aeth_fft_mul_ifft_demod(p, (const aeth_cf32 *)dc, cnt, cnt / N, c.sig_dev, c.n_sig, c.scale_kind_fwd, c.x_fwd,
                                            c.scale_kind_bwd, c.x_bwd, c.bits_per_symbol, c.table_host, (uint8_t *)dout, cnt_out, c.compat);
         };
         return AETH_OK;
     case AETH_STREAM_FFT_INTERPOLATE:                // the transform, then sampling::interpolate per frame (BASELINE config 5)
         op.out_per_align = N + (N - 1) * c.n_between;
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out, void *, void *) {
             size_t wrote = 0;
             int rc = aeth_fft_exec_interpolate(p, (const aeth_cf32 *)dc, cnt, cnt / N, c.sign, c.scale_kind_fwd, c.x_fwd, (aeth_cf32 *)dout,
                                                cnt_out, c.n_between, c.compat, &wrote);
@@ -476,6 +490,82 @@ int make_op(aeth_ctx *ctx, const aeth_stream_op *d, StageOp &op)
     default:
         return aeth::set_error(AETH_E_ARG, "unknown stream op %d", d->kind);
     }
+}
+
+// ---- a chain of ops as ONE compute stage: pipeline::new(..).add_stage(a).add_stage(b) (src/pipeline.rs:24-41) ------------
+// Stage i's output is stage i + 1's input on the device; only the first stage sees host data and only the last one's
+// output goes back.  The chunk granule is the smallest number of input elements that every stage takes in whole
+// hops / frames; intermediates ping-pong between the slot's two scratch buffers (an in-place stage leaves its result
+// where its input was).
+size_t gcd_sz(size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; }
+
+int make_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, StageOp &out)
+{
+    AETH_REQUIRE(ops && n_ops >= 1 && n_ops <= 8, AETH_E_ARG, "a pipeline has 1 .. 8 compute ops");
+    if (n_ops == 1) return make_op(ctx, &ops[0], out);
+    auto st = std::make_shared<std::vector<StageOp>>(n_ops);
+    for (size_t i = 0; i < n_ops; i++) {
+        int rc = make_op(ctx, &ops[i], (*st)[i]); if (rc) return rc;
+        AETH_REQUIRE(i == 0 || (*st)[i].hist == 0, AETH_E_UNSUPPORTED, "stage %zu: a filter (left context) can only be the first stage", i);
+        AETH_REQUIRE(i + 1 == n_ops || (*st)[i].out_unit == sizeof(aeth_cf32), AETH_E_ARG, "stage %zu emits bits: it has to be the last stage", i);
+    }
+    // granule U: every stage's input count is a multiple of its own granule
+    size_t U = (*st)[0].align;
+    for (int guard = 0; guard < 64; guard++) {
+        size_t c = U; bool ok = true;
+        for (size_t i = 0; i < n_ops; i++) {
+            const size_t g = (*st)[i].align;
+            if (c % g) { U *= g / gcd_sz(c, g); ok = false; break; }
+            c = (*st)[i].out_count(c);
+        }
+        if (ok) break;
+        AETH_REQUIRE(guard < 63 && U < ((size_t)1 << 40), AETH_E_UNSUPPORTED, "the stages' chunk granules do not fit together");
+    }
+    out = StageOp();
+    out.ctx = ctx; out.hist = (*st)[0].hist; out.align = U; out.out_unit = (*st)[n_ops - 1].out_unit;
+    size_t c = U, mid = 0; bool all_inplace = true;
+    for (size_t i = 0; i < n_ops; i++) {
+        const size_t co = (*st)[i].out_count(c);
+        all_inplace = all_inplace && (*st)[i].inplace;
+        if (!(*st)[i].inplace && co * sizeof(aeth_cf32) > mid) mid = co * sizeof(aeth_cf32);
+        c = co;
+    }
+    out.out_per_align = c; out.inplace = all_inplace; out.mid_per_align = all_inplace ? 0 : mid;
+    out.run = [st, n_ops](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out, void *m0, void *m1) -> int {
+        void *mids[2] = {m0, m1};
+        int which = 0;
+        const void *cur_hist = dh; void *cur = dc; size_t c = cnt;
+        for (size_t i = 0; i < n_ops; i++) {
+            const StageOp &o = (*st)[i];
+            const size_t co = o.out_count(c);
+            const bool last = i + 1 == n_ops;
+            if (o.inplace) {
+                int rc = o.run(s, cur_hist, cur, have_hist, c, nullptr, co, nullptr, nullptr); if (rc) return rc;
+            } else {
+                void *dst = last ? dout : mids[which]; which ^= 1;
+                int rc = o.run(s, cur_hist, cur, have_hist, c, dst, co, nullptr, nullptr); if (rc) return rc;
+                cur = dst;
+            }
+            have_hist = false; cur_hist = cur; c = co;
+        }
+        if (c != cnt_out) return aeth::set_error(AETH_E_LEN, "the chain produced %zu of %zu elements", c, cnt_out);
+        // an in-place last stage behind an out-of-place one leaves the result in scratch: hand it to the download
+        if (cur != dout && dout && cur != dc) {
+            const hipError_t e = hipMemcpyAsync(dout, cur, c * (*st)[n_ops - 1].out_unit, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return aeth::hip_fail(e, "hipMemcpyAsync D2D");
+        }
+        return AETH_OK;
+    };
+    return AETH_OK;
+}
+
+int stream_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, const void *in, size_t n_in, void *out, size_t n_out,
+                 size_t chunk, aeth_pipe_stats *stats, aeth_pipe_util *util)
+{
+    StageOp op;
+    int rc = make_chain(ctx, ops, n_ops, op); if (rc) return rc;
+    AETH_REQUIRE(n_in % op.align == 0, AETH_E_LEN, "a chain of stages takes whole granules of %zu samples (" AETH_MSG_FFT_LEN ")", op.align);
+    return stream_host(op, nullptr, in, n_in, out, n_out, chunk, stats, util);
 }
 
 int stream_any(aeth_ctx *ctx, const aeth_stream_op *d, const void *in, size_t n_in, void *out, size_t n_out, size_t chunk,
@@ -505,6 +595,22 @@ int aeth_stream_host_util(aeth_ctx *ctx, const aeth_stream_op *op, const void *i
 {
     AETH_REQUIRE(util, AETH_E_ARG, "util is null");
     return stream_any(ctx, op, in, n_in, out, n_out, chunk, nullptr, util);
+}
+
+/* pipeline::new(..).add_stage(a).add_stage(b)...: several ops as one compute stage (see make_chain) */
+int aeth_stream_host_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, const void *in, size_t n_in, void *out, size_t n_out,
+                           size_t chunk, aeth_pipe_stats *stats, aeth_pipe_util *util)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    if (n_ops == 1 && ops) return stream_any(ctx, ops, in, n_in, out, n_out, chunk, stats, util);
+    return stream_chain(ctx, ops, n_ops, in, n_in, out, n_out, chunk, stats, util);
+}
+
+size_t aeth_stream_chain_out_count(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, size_t n_in)
+{
+    StageOp so;
+    if (!ctx || make_chain(ctx, ops, n_ops, so) != AETH_OK) return 0;
+    return so.out_count(n_in);
 }
 
 size_t aeth_stream_out_count(aeth_ctx *ctx, const aeth_stream_op *op, size_t n_in)

@@ -110,3 +110,29 @@ def run_file(stage, in_path, out_path, chunk=0):
     s = _Stats()
     check(_lib.load().aeth_stream_file(stage.ctx.h, C.byref(stage.op), os.fsencode(in_path), os.fsencode(out_path), chunk, C.byref(s)))
     return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+
+def run_chain(stages, x, out=None, chunk=0, report=False):
+    """`pipeline::new(..).add_stage(a).add_stage(b)` (src/pipeline.rs:24-41): several stages as ONE compute stage -- stage
+    i's output is stage i + 1's input on the device; only `x` goes up and only the last stage's output comes back.
+    Returns (out, stats); report=True adds the per-stage busy seconds and `lines` as `run` does."""
+    lib = _lib.load()
+    ctx = stages[0].ctx
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    ops = (_Op * len(stages))(*[s.op for s in stages])
+    n_out = lib.aeth_stream_chain_out_count(ctx.h, ops, len(stages), x.size)
+    dt = stages[-1].out_dtype
+    if out is None:
+        out = np.empty(n_out, dt)
+    assert out.dtype == dt and out.flags["C_CONTIGUOUS"]
+    s, u = _Stats(), _Util()
+    check(lib.aeth_stream_host_chain(ctx.h, ops, len(stages), x.ctypes.data_as(C.c_void_p), x.size, out.ctypes.data_as(C.c_void_p),
+                                     out.size, chunk, None if report else C.byref(s), C.byref(u) if report else None))
+    if not report:
+        return out, {k: getattr(s, k) for k, _ in _Stats._fields_}
+    st = {k: getattr(u, k) for k, _ in _Util._fields_}
+    act = (u.active_copy_in, u.active_upload, u.active_kernel, u.active_download, u.active_copy_out)
+    st["lines"] = [f"Stage: {name:15} : Processed {int(u.chunks)} in {u.seconds:3.3f}s ({u.chunks / u.seconds:9.2f}/s); "
+                   f"Utilisation: {a / u.seconds * 100.0:3.2f}%"
+                   for name, a in zip(_STAGE_NAMES, act) if not (name.startswith("copy") and a == 0)] if u.seconds > 0 else []
+    return out, st

@@ -330,6 +330,16 @@ typedef struct { double seconds, samples, chunks, pinned, active_upload, active_
                  active_copy_in, active_copy_out; /* the two host stages (0 for a side copied directly) */ } aeth_pipe_util;
 AETH_API int aeth_stream_host_util(aeth_ctx *ctx, const aeth_stream_op *op, const void *in_host, size_t n_in,
                                    void *out_host, size_t n_out, size_t chunk_samples, aeth_pipe_util *util);
+/* Several ops as ONE compute stage -- `pipeline::new(..).add_stage(a).add_stage(b)` (src/pipeline.rs:24-41): stage i's output
+ * is stage i + 1's input on the device, only the first stage sees host data and only the last one's output goes back (so
+ * e.g. FIR -> FFT frames -> correlate + demod moves 8 B up and 2 B down per sample).  1 .. 8 ops; a filter can only be the
+ * first stage, a stage that emits bits only the last; n_in has to be a whole number of the chain's granule (the smallest
+ * count every stage takes in whole hops / frames).  Bit-identical to the ops' device flavours applied one after the
+ * other.  stats and util may each be NULL. */
+AETH_API size_t aeth_stream_chain_out_count(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, size_t n_in);
+AETH_API int aeth_stream_host_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, const void *in_host, size_t n_in,
+                                    void *out_host, size_t n_out, size_t chunk_samples, aeth_pipe_stats *stats,
+                                    aeth_pipe_util *util);
 /* AETH_STREAM_FIR with the filter as the only argument (output bit-identical to aeth_fir_exec_host on the whole slice) */
 AETH_API int aeth_fir_stream_host(aeth_fir *fir, const aeth_cf32 *in_host, size_t n, aeth_cf32 *out_host,
                                   size_t chunk_samples, aeth_pipe_stats *stats);

@@ -146,6 +146,9 @@ extern "C" {
                             n_out: usize, chunk: usize, stats: *mut aeth_pipe_stats) -> c_int;
     pub fn aeth_stream_host_util(ctx: *mut aeth_ctx, op: *const aeth_stream_op, inp: *const c_void, n_in: usize, out: *mut c_void,
                                  n_out: usize, chunk: usize, util: *mut aeth_pipe_util) -> c_int;
+    pub fn aeth_stream_chain_out_count(ctx: *mut aeth_ctx, ops: *const aeth_stream_op, n_ops: usize, n_in: usize) -> usize;
+    pub fn aeth_stream_host_chain(ctx: *mut aeth_ctx, ops: *const aeth_stream_op, n_ops: usize, inp: *const c_void, n_in: usize,
+                                  out: *mut c_void, n_out: usize, chunk: usize, stats: *mut aeth_pipe_stats, util: *mut aeth_pipe_util) -> c_int;
     pub fn aeth_ctx_trim(ctx: *mut aeth_ctx) -> c_int;
     pub fn aeth_test_fail_staging_after(n: c_int);
     pub fn aeth_fir_stream_host(fir: *mut aeth_fir, inp: *const cf32, n: usize, out: *mut cf32, chunk: usize,

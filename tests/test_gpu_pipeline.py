@@ -192,3 +192,56 @@ def _free_bytes():
     free, total = C.c_size_t(0), C.c_size_t(0)
     assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
     return free.value
+
+
+# ---- several ops as one compute stage: pipeline::new(..).add_stage(a).add_stage(b) (pipeline.rs:24-41) -----------------
+def test_chain_fir_then_fft_then_correlate_demod(ctx, plan, sig):
+    """8 B up, 2 B down per sample; the intermediates never leave the device; bits of the three device calls in a row"""
+    f = Fir(ctx, rand_c64(1, 64, scale=0.2), 2048)
+    granule = 1984 * 2048 // np.gcd(1984, 2048)              # whole hops AND whole frames: lcm(1984, 2048) = 63488
+    n = granule * 9
+    x = rand_c64(5, n)
+    stages = [pipeline.Stage.fir(f), pipeline.Stage.fft(plan, Scale.SN), pipeline.Stage.correlate_demod(plan, sig, 2)]
+    d = f.filter(ctx.vec(x)); plan.ifwd(d, Scale.SN)
+    want = modulation.qpsk(ctx).correlate_demod(plan, d, sig).to_host()
+    for chunk in (0, granule, granule * 4):
+        y, st = pipeline.run_chain(stages, x, chunk=chunk)
+        assert y.dtype == np.uint8 and np.array_equal(y, want), chunk
+    y, st = pipeline.run_chain(stages, x, report=True)
+    assert np.array_equal(y, want) and len(st["lines"]) == 5
+    with pytest.raises(ap.AetherError, match="granules"):
+        pipeline.run_chain(stages, x[: granule + 2048])       # whole frames, but not whole hops of the filter's chunks
+
+
+@pytest.mark.parametrize("frames,chunk", [(7, 0), (300, N * 32)])
+def test_chain_with_in_place_stages(ctx, plan, sig, frames, chunk):
+    """the correlator chain runs in place: first (on the slot), last (in scratch, copied to the download buffer), alone"""
+    x = rand_c64(frames, frames * N)
+    # in place first, out of place last: correlator chain -> FFT + interpolate
+    o = ctx.empty((N + (N - 1) * 2) * frames); d = ctx.vec(x); plan.mul_chain(d, sig); plan.rfft_interpolate(d, o, 2, Scale.SN)
+    y, _ = pipeline.run_chain([pipeline.Stage.mul_chain(plan, sig), pipeline.Stage.fft_interpolate(plan, 2, Scale.SN)], x, chunk=chunk)
+    assert bits_equal(y, o.to_host())
+    # out of place first, in place last: FFT frames -> correlator chain
+    d = ctx.vec(x); plan.ifwd(d, Scale.SN); plan.mul_chain(d, sig, Scale.NONE, Scale.N)
+    y, _ = pipeline.run_chain([pipeline.Stage.fft(plan, Scale.SN), pipeline.Stage.mul_chain(plan, sig, Scale.NONE, Scale.N)], x, chunk=chunk)
+    assert bits_equal(y, d.to_host())
+    # every stage in place
+    d = ctx.vec(x); plan.mul_chain(d, sig); plan.mul_chain(d, sig, Scale.SN, Scale.SN)
+    y, _ = pipeline.run_chain([pipeline.Stage.mul_chain(plan, sig), pipeline.Stage.mul_chain(plan, sig, Scale.SN, Scale.SN)], x, chunk=chunk)
+    assert bits_equal(y, d.to_host())
+    # a chain of one is the plain call
+    y, _ = pipeline.run_chain([pipeline.Stage.fft(plan, Scale.SN)], x, chunk=chunk)
+    assert bits_equal(y, pipeline.run(pipeline.Stage.fft(plan, Scale.SN), x)[0])
+
+
+def test_chain_rules(ctx, plan, sig):
+    f = Fir(ctx, rand_c64(1, 64, scale=0.2), 2048)
+    x = rand_c64(1, 63488)
+    with pytest.raises(ap.AetherError, match="first stage"):
+        pipeline.run_chain([pipeline.Stage.fft(plan), pipeline.Stage.fir(f)], x)
+    with pytest.raises(ap.AetherError, match="last stage"):
+        pipeline.run_chain([pipeline.Stage.correlate_demod(plan, sig, 2), pipeline.Stage.fft(plan)], x)
+    small = HipFft(ctx, 512)
+    y, _ = pipeline.run_chain([pipeline.Stage.fft(plan, Scale.SN), pipeline.Stage.fft(small, Scale.SN)], x[: 2048 * 6])   # 2048-frames, then 512-frames
+    d = ctx.vec(x[: 2048 * 6]); plan.ifwd(d, Scale.SN); small.ifwd(d, Scale.SN)
+    assert bits_equal(y, d.to_host())
