@@ -90,8 +90,9 @@ struct StageOp {
                                            // intermediates ping-pong between two scratch buffers of the slot)
     // din_chunk: first input element of the chunk in the device slot (hist elements of context in front of it when
     // have_hist); runs on `s` and must not wait for the host; mid0 / mid1: the slot's scratch pair (chains only)
+    // first: index in the stream of the chunk's first input element (position-addressed ops: the noise generator)
     std::function<int(hipStream_t s, const void *din_hist, void *din_chunk, bool have_hist, size_t cnt, void *dout, size_t cnt_out,
-                      void *mid0, void *mid1)> run;
+                      void *mid0, void *mid1, size_t first)> run;
     size_t out_count(size_t cnt) const { return cnt / align * out_per_align + (cnt % align) * out_per_align / align; }
 };
 
@@ -347,7 +348,7 @@ int stream_host(const StageOp &op, const void *hist, const void *in_, size_t n, 
                 if (!ok(hipStreamWaitEvent(s_run, ps->up[s], 0), "hipStreamWaitEvent")) break;
                 if (used && !ok(hipStreamWaitEvent(s_run, ps->down[s], 0), "hipStreamWaitEvent")) break;
                 mark(k, 1, 0, s_run);
-                rc = op.run(s_run, din, din + nh * IU, (o0 || hist) && nh, cnt, dout, cnt_out, ps->mid[s][0], ps->mid[s][1]);
+                rc = op.run(s_run, din, din + nh * IU, (o0 || hist) && nh, cnt, dout, cnt_out, ps->mid[s][0], ps->mid[s][1], o0);
                 if (rc) break;
                 mark(k, 1, 1, s_run);
                 if (!ok(hipEventRecord(ps->ran[s], s_run), "hipEventRecord")) break;
@@ -425,7 +426,7 @@ int op_fir(aeth_fir *f, StageOp &op)
 {
     AETH_REQUIRE(f, AETH_E_ARG, "fir is null");
     op.ctx = f->ctx; op.hist = f->ntaps - 1; op.align = f->hop; op.out_per_align = f->hop;
-    op.run = [f](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t, void *, void *) {
+    op.run = [f](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t, void *, void *, size_t) {
         return aeth::fir_exec_on(f, s, have_hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout);
     };
     return AETH_OK;
@@ -444,11 +445,24 @@ int make_op(aeth_ctx *ctx, const aeth_stream_op *d, StageOp &op)
             const size_t dec = d->n_between;
             AETH_REQUIRE(dec >= 1 && f->hop % dec == 0, AETH_E_ARG, "decimation %zu must divide the filter's hop (%zu)", dec, f->hop);
             op.out_per_align = f->hop / dec;
-            op.run = [f, dec](hipStream_t, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out, void *, void *) {
+            op.run = [f, dec](hipStream_t, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out, void *, void *, size_t) {
                 if (cnt % dec != 0) return aeth::set_error(AETH_E_ARG, AETH_MSG_DECIM);          /* sampling.rs:32-36 */
                 return aeth_fir_exec_decim(f, have_hist ? (const aeth_cf32 *)dh : nullptr, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout, cnt_out);
             };
         }
+        return AETH_OK;
+    }
+    if (d->kind == AETH_STREAM_MODULATE_AWGN) {
+        // Modulation::modulate, then Awgn::apply on the fresh symbols (examples/modem.rs:19-26): bit bytes in, symbols out;
+        // the noise is addressed by position in the stream, so chunks draw what the one-shot call would
+        const aeth_stream_op c = *d;
+        AETH_REQUIRE(c.bits_per_symbol == 1 || c.bits_per_symbol == 2, AETH_E_UNSUPPORTED, "bits_per_symbol %d: BPSK (1) or QPSK (2)", c.bits_per_symbol);
+        const size_t bps = (size_t)c.bits_per_symbol;
+        op.ctx = ctx; op.in_unit = 1; op.out_unit = sizeof(aeth_cf32); op.align = 2 * bps; op.out_per_align = 2;   // whole pairs of symbols: the generator draws per pair
+        op.run = [ctx, c, bps](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out, void *, void *, size_t first) {
+            return aeth_modulate_awgn(ctx, (const uint8_t *)dc, cnt, c.bits_per_symbol, c.table_host, (aeth_cf32 *)dout, cnt_out, c.x_fwd, c.seed,
+                                      c.offset + first / bps);
+        };
         return AETH_OK;
     }
     aeth_fft *p = d->fft;
@@ -459,27 +473,27 @@ int make_op(aeth_ctx *ctx, const aeth_stream_op *d, StageOp &op)
     const aeth_stream_op c = *d;                     // by value: the descriptor need not outlive the call, but does anyway
     switch (d->kind) {
     case AETH_STREAM_FFT:                            // Fft::fwd / bwd over chunks_mut(fft_len) (src/util/plot.rs:59-61)
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t, void *, void *) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t, void *, void *, size_t) {
             return aeth_fft_exec(p, (const aeth_cf32 *)dc, cnt, (aeth_cf32 *)dout, cnt / N, c.sign, c.scale_kind_fwd, c.x_fwd);
         };
         return AETH_OK;
     case AETH_STREAM_FFT_MUL_IFFT:                   // benches/benches.rs:410-416, in place
         op.inplace = true;
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *, size_t, void *, void *) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *, size_t, void *, void *, size_t) {
             return aeth_fft_mul_ifft(p, (aeth_cf32 *)dc, cnt, cnt / N, c.sig_dev, c.n_sig, c.scale_kind_fwd, c.x_fwd, c.scale_kind_bwd, c.x_bwd);
         };
         return AETH_OK;
     case AETH_STREAM_FFT_MUL_IFFT_DEMOD:             // ... then Modulation::demod_naive (examples/modem.rs:28-31)
         AETH_REQUIRE(c.bits_per_symbol == 1 || c.bits_per_symbol == 2, AETH_E_UNSUPPORTED, "bits_per_symbol %d: BPSK (1) or QPSK (2)", c.bits_per_symbol);
         op.out_unit = 1; op.out_per_align = N * (size_t)c.bits_per_symbol;
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out, void *, void *) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out, void *, void *, size_t) {
             return aeth_fft_mul_ifft_demod(p, (const aeth_cf32 *)dc, cnt, cnt / N, c.sig_dev, c.n_sig, c.scale_kind_fwd, c.x_fwd,
                                            c.scale_kind_bwd, c.x_bwd, c.bits_per_symbol, c.table_host, (uint8_t *)dout, cnt_out, c.compat);
         };
         return AETH_OK;
     case AETH_STREAM_FFT_INTERPOLATE:                // the transform, then sampling::interpolate per frame (BASELINE config 5)
         op.out_per_align = N + (N - 1) * c.n_between;
-        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out, void *, void *) {
+        op.run = [p, c, N](hipStream_t, const void *, void *dc, bool, size_t cnt, void *dout, size_t cnt_out, void *, void *, size_t) {
             size_t wrote = 0;
             int rc = aeth_fft_exec_interpolate(p, (const aeth_cf32 *)dc, cnt, cnt / N, c.sign, c.scale_kind_fwd, c.x_fwd, (aeth_cf32 *)dout,
                                                cnt_out, c.n_between, c.compat, &wrote);
@@ -508,6 +522,7 @@ int make_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, StageOp &
         int rc = make_op(ctx, &ops[i], (*st)[i]); if (rc) return rc;
         AETH_REQUIRE(i == 0 || (*st)[i].hist == 0, AETH_E_UNSUPPORTED, "stage %zu: a filter (left context) can only be the first stage", i);
         AETH_REQUIRE(i + 1 == n_ops || (*st)[i].out_unit == sizeof(aeth_cf32), AETH_E_ARG, "stage %zu emits bits: it has to be the last stage", i);
+        AETH_REQUIRE(i == 0 || (*st)[i].in_unit == sizeof(aeth_cf32), AETH_E_ARG, "stage %zu takes bits: it has to be the first stage", i);
     }
     // granule U: every stage's input count is a multiple of its own granule
     size_t U = (*st)[0].align;
@@ -522,7 +537,7 @@ int make_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, StageOp &
         AETH_REQUIRE(guard < 63 && U < ((size_t)1 << 40), AETH_E_UNSUPPORTED, "the stages' chunk granules do not fit together");
     }
     out = StageOp();
-    out.ctx = ctx; out.hist = (*st)[0].hist; out.align = U; out.out_unit = (*st)[n_ops - 1].out_unit;
+    out.ctx = ctx; out.hist = (*st)[0].hist; out.align = U; out.in_unit = (*st)[0].in_unit; out.out_unit = (*st)[n_ops - 1].out_unit;
     size_t c = U, mid = 0; bool all_inplace = true;
     for (size_t i = 0; i < n_ops; i++) {
         const size_t co = (*st)[i].out_count(c);
@@ -531,7 +546,7 @@ int make_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, StageOp &
         c = co;
     }
     out.out_per_align = c; out.inplace = all_inplace; out.mid_per_align = all_inplace ? 0 : mid;
-    out.run = [st, n_ops](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out, void *m0, void *m1) -> int {
+    out.run = [st, n_ops](hipStream_t s, const void *dh, void *dc, bool have_hist, size_t cnt, void *dout, size_t cnt_out, void *m0, void *m1, size_t first) -> int {
         void *mids[2] = {m0, m1};
         int which = 0;
         const void *cur_hist = dh; void *cur = dc; size_t c = cnt;
@@ -540,13 +555,13 @@ int make_chain(aeth_ctx *ctx, const aeth_stream_op *ops, size_t n_ops, StageOp &
             const size_t co = o.out_count(c);
             const bool last = i + 1 == n_ops;
             if (o.inplace) {
-                int rc = o.run(s, cur_hist, cur, have_hist, c, nullptr, co, nullptr, nullptr); if (rc) return rc;
+                int rc = o.run(s, cur_hist, cur, have_hist, c, nullptr, co, nullptr, nullptr, first); if (rc) return rc;
             } else {
                 void *dst = last ? dout : mids[which]; which ^= 1;
-                int rc = o.run(s, cur_hist, cur, have_hist, c, dst, co, nullptr, nullptr); if (rc) return rc;
+                int rc = o.run(s, cur_hist, cur, have_hist, c, dst, co, nullptr, nullptr, first); if (rc) return rc;
                 cur = dst;
             }
-            have_hist = false; cur_hist = cur; c = co;
+            have_hist = false; cur_hist = cur; first = o.out_count(first); c = co;
         }
         if (c != cnt_out) return aeth::set_error(AETH_E_LEN, "the chain produced %zu of %zu elements", c, cnt_out);
         // an in-place last stage behind an out-of-place one leaves the result in scratch: hand it to the download
@@ -575,6 +590,8 @@ int stream_any(aeth_ctx *ctx, const aeth_stream_op *d, const void *in, size_t n_
     int rc = make_op(ctx, d, op); if (rc) return rc;
     if (d->kind == AETH_STREAM_FIR_DECIM)
         AETH_REQUIRE(n_in % d->n_between == 0, AETH_E_ARG, AETH_MSG_DECIM);           /* sampling.rs:32-36 */
+    else if (d->kind == AETH_STREAM_MODULATE_AWGN)
+        AETH_REQUIRE(n_in % (size_t)d->bits_per_symbol == 0, AETH_E_LEN, "bit count %zu is not a multiple of BITS_PER_SYMBOL %d", n_in, d->bits_per_symbol);
     else if (d->kind != AETH_STREAM_FIR)
         AETH_REQUIRE(n_in % op.align == 0, AETH_E_LEN, AETH_MSG_FFT_LEN);             /* fft.rs:163-167: whole frames only */
     return stream_host(op, nullptr, in, n_in, out, n_out, chunk, stats, util);

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import check
 from .fft import Scale, SIGN_REF_FWD
 
-FIR, FFT, FFT_MUL_IFFT, FFT_MUL_IFFT_DEMOD, FFT_INTERPOLATE, FIR_DECIM = range(6)
+FIR, FFT, FFT_MUL_IFFT, FFT_MUL_IFFT_DEMOD, FFT_INTERPOLATE, FIR_DECIM, MODULATE_AWGN = range(7)
 
 
 class _Op(C.Structure):
@@ -19,7 +19,7 @@ class _Op(C.Structure):
     _fields_ = [("kind", C.c_int), ("fir", C.c_void_p), ("fft", C.c_void_p), ("sig_dev", C.c_void_p), ("n_sig", C.c_size_t),
                 ("sign", C.c_int), ("scale_kind_fwd", C.c_int), ("x_fwd", C.c_float), ("scale_kind_bwd", C.c_int),
                 ("x_bwd", C.c_float), ("bits_per_symbol", C.c_int), ("table_host", C.c_void_p), ("compat", C.c_int),
-                ("n_between", C.c_size_t)]
+                ("n_between", C.c_size_t), ("seed", C.c_uint64), ("offset", C.c_uint64)]
 
 
 class _Stats(C.Structure):
@@ -34,12 +34,23 @@ class _Util(C.Structure):
 class Stage:
     """The compute stage of a host pipeline: an op descriptor plus whatever keeps its operands alive."""
 
+    in_dtype = np.complex64
+
     def __init__(self, ctx, op, out_dtype, keep=()):
         self.ctx, self.op, self.out_dtype, self._keep = ctx, op, out_dtype, keep
 
     @staticmethod
     def fir(f):
         return Stage(f.ctx, _Op(kind=FIR, fir=f.h), np.complex64, (f,))
+
+    @staticmethod
+    def modulate_awgn(ctx, bits_per_symbol, power, seed, offset=0, table=None):
+        """Modulation::modulate, then Awgn::apply on the fresh symbols (examples/modem.rs:19-26): BIT BYTES in, symbols out"""
+        tab = None if table is None else np.ascontiguousarray(table, dtype=np.complex64)
+        st = Stage(ctx, _Op(kind=MODULATE_AWGN, bits_per_symbol=bits_per_symbol, table_host=None if tab is None else tab.ctypes.data,
+                            x_fwd=float(np.float32(power)), seed=int(seed), offset=int(offset)), np.complex64, (tab,))
+        st.in_dtype = np.uint8
+        return st
 
     @staticmethod
     def fir_decim(f, dec):
@@ -83,7 +94,7 @@ def run(stage, x, out=None, chunk=0, report=False):
     """x (host cf32 array) through copy-in | upload | stage | download | copy-out; returns (out, stats).  report=True
     adds the seconds each stage was active and `lines` in the format of the reference's report (pipeline.rs:101-108)."""
     lib = _lib.load()
-    x = np.ascontiguousarray(x, dtype=np.complex64)
+    x = np.ascontiguousarray(x, dtype=stage.in_dtype)
     n_out = stage.out_count(x.size)
     if out is None:
         out = np.empty(n_out, stage.out_dtype)
@@ -118,7 +129,7 @@ def run_chain(stages, x, out=None, chunk=0, report=False):
     Returns (out, stats); report=True adds the per-stage busy seconds and `lines` as `run` does."""
     lib = _lib.load()
     ctx = stages[0].ctx
-    x = np.ascontiguousarray(x, dtype=np.complex64)
+    x = np.ascontiguousarray(x, dtype=stages[0].in_dtype)
     ops = (_Op * len(stages))(*[s.op for s in stages])
     n_out = lib.aeth_stream_chain_out_count(ctx.h, ops, len(stages), x.size)
     dt = stages[-1].out_dtype

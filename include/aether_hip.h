@@ -286,6 +286,8 @@ AETH_API int aeth_host_is_pinned(const void *ptr, size_t bytes);        /* 1: in
  *   AETH_STREAM_FFT_MUL_IFFT        fft, sig_dev, both scales                  frames -> frames (= aeth_fft_mul_ifft)
  *   AETH_STREAM_FFT_MUL_IFFT_DEMOD  ... + bits_per_symbol, table_host, compat  8 B in -> bits_per_symbol BYTES out per sample
  *   AETH_STREAM_FFT_INTERPOLATE     fft, sign, scale, n_between, compat (= compat_im)   len in -> len + (len-1)*n_between out per frame
+ *   AETH_STREAM_MODULATE_AWGN       bits_per_symbol, table_host, x_fwd = noise power, seed, offset   BIT BYTES in -> symbols out (= aeth_modulate_awgn;
+ *                                   the one op whose input is not cf32: in_host holds n_in bytes; in a chain it has to be the first stage)
  *   AETH_STREAM_FIR_DECIM           fir, n_between = dec (must divide aeth_fir_hop and n_in)   n in -> n / dec out (= aeth_fir_exec_decim)
  * Every op's output is bit-identical to its device flavour on the whole slice.  n_in counts input samples, n_out
  * output ELEMENTS of the op's type and must equal aeth_stream_out_count(ctx, op, n_in) (AETH_E_LEN otherwise; the frame
@@ -304,7 +306,7 @@ AETH_API int aeth_host_is_pinned(const void *ptr, size_t bytes);        /* 1: in
  * of it back (and the device scratch of the host-slice flavours), aeth_ctx_destroy does the same. */
 typedef struct { double seconds, samples, chunks, pinned; } aeth_pipe_stats;
 enum { AETH_STREAM_FIR = 0, AETH_STREAM_FFT = 1, AETH_STREAM_FFT_MUL_IFFT = 2, AETH_STREAM_FFT_MUL_IFFT_DEMOD = 3,
-       AETH_STREAM_FFT_INTERPOLATE = 4, AETH_STREAM_FIR_DECIM = 5 };
+       AETH_STREAM_FFT_INTERPOLATE = 4, AETH_STREAM_FIR_DECIM = 5, AETH_STREAM_MODULATE_AWGN = 6 };
 typedef struct aeth_stream_op {
     int kind;                          /* AETH_STREAM_*                                                          */
     aeth_fir *fir;                     /* FIR                                                                    */
@@ -318,6 +320,7 @@ typedef struct aeth_stream_op {
     const aeth_cf32 *table_host;       /*   symbol table (host), NULL = the generic tables                       */
     int compat;                        /*   as aeth_demod_naive; FFT_INTERPOLATE: compat_im of aeth_interpolate  */
     size_t n_between;                  /* FFT_INTERPOLATE; FIR_DECIM: the decimation                             */
+    uint64_t seed, offset;             /* MODULATE_AWGN: noise stream and the position of the first symbol in it  */
 } aeth_stream_op;
 AETH_API size_t aeth_stream_out_count(aeth_ctx *ctx, const aeth_stream_op *op, size_t n_in);   /* 0 for a bad op */
 AETH_API int aeth_stream_host(aeth_ctx *ctx, const aeth_stream_op *op, const void *in_host, size_t n_in,

@@ -24,13 +24,15 @@ pub const AETH_VEC_ADD: c_int = 4; pub const AETH_VEC_SUB: c_int = 5; pub const 
 #[derive(Clone, Copy)]
 pub struct aeth_stream_op { pub kind: c_int, pub fir: *mut aeth_fir, pub fft: *mut aeth_fft, pub sig_dev: *const cf32, pub n_sig: usize,
                             pub sign: c_int, pub scale_kind_fwd: c_int, pub x_fwd: c_float, pub scale_kind_bwd: c_int, pub x_bwd: c_float,
-                            pub bits_per_symbol: c_int, pub table_host: *const cf32, pub compat: c_int, pub n_between: usize }
+                            pub bits_per_symbol: c_int, pub table_host: *const cf32, pub compat: c_int, pub n_between: usize,
+                            pub seed: u64, pub offset: u64 }
 pub const AETH_STREAM_FIR: c_int = 0;
 pub const AETH_STREAM_FFT: c_int = 1;
 pub const AETH_STREAM_FFT_MUL_IFFT: c_int = 2;
 pub const AETH_STREAM_FFT_MUL_IFFT_DEMOD: c_int = 3;
 pub const AETH_STREAM_FFT_INTERPOLATE: c_int = 4;
 pub const AETH_STREAM_FIR_DECIM: c_int = 5;
+pub const AETH_STREAM_MODULATE_AWGN: c_int = 6;
 /// aeth_pipe_util: the same plus the seconds each stage (upload, kernel, download) was active -- the per-stage
 /// utilisation report of src/pipeline.rs:89-114
 #[repr(C)]

@@ -232,7 +232,7 @@ impl<'c> Stage<'c> {
     fn blank(ctx: &'c Context, kind: std::os::raw::c_int) -> Stage<'c> {
         Stage { ctx, op: aeth_stream_op { kind, fir: ptr::null_mut(), fft: ptr::null_mut(), sig_dev: ptr::null(), n_sig: 0, sign: 0,
                                           scale_kind_fwd: 0, x_fwd: 0.0, scale_kind_bwd: 0, x_bwd: 0.0, bits_per_symbol: 0,
-                                          table_host: ptr::null(), compat: 0, n_between: 0 } }
+                                          table_host: ptr::null(), compat: 0, n_between: 0, seed: 0, offset: 0 } }
     }
     pub fn fir(ctx: &'c Context, f: &Fir<'c>) -> Stage<'c> { let mut s = Stage::blank(ctx, AETH_STREAM_FIR); s.op.fir = f.h; s }
     /// `Fft::fwd` over `chunks_mut(fft_len)` (src/util/plot.rs:59-61)

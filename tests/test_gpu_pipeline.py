@@ -245,3 +245,36 @@ def test_chain_rules(ctx, plan, sig):
     y, _ = pipeline.run_chain([pipeline.Stage.fft(plan, Scale.SN), pipeline.Stage.fft(small, Scale.SN)], x[: 2048 * 6])   # 2048-frames, then 512-frames
     d = ctx.vec(x[: 2048 * 6]); plan.ifwd(d, Scale.SN); small.ifwd(d, Scale.SN)
     assert bits_equal(y, d.to_host())
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+def test_modem_as_a_host_pipeline(ctx, plan, sig, bps):
+    """BASELINE config 4's channel end to end over host memory (examples/modem.rs:15-32 behind the correlator): bit bytes up,
+    modulate + AWGN -> correlate -> demodulate on the device, bit bytes down.  The noise is addressed by stream position,
+    so every chunking draws what the one-shot device calls draw."""
+    from aether_primitives_amd import noise
+    frames = 90
+    bits = np.random.default_rng(3).integers(0, 2, bps * N * frames, dtype=np.uint8)
+    m = modulation.qpsk(ctx) if bps == 2 else modulation.bpsk(ctx)
+    tx = m.modulate_awgn(bits, noise.new(ctx, 0.01, 4711))
+    want_tx = tx.to_host()
+    want = m.correlate_demod(plan, tx, sig).to_host()
+    mod = pipeline.Stage.modulate_awgn(ctx, bps, 0.01, 4711)
+    for chunk in (0, bps * N * 7, bps * N * 64):
+        y, _ = pipeline.run(mod, bits, chunk=chunk)                      # the source stage alone: bits in, symbols out
+        assert y.dtype == np.complex64 and bits_equal(y, want_tx), chunk
+        rx, _ = pipeline.run_chain([mod, pipeline.Stage.correlate_demod(plan, sig, bps)], bits, chunk=chunk)
+        assert rx.dtype == np.uint8 and rx.size == bits.size and np.array_equal(rx, want), chunk
+    # a stream that starts in the middle of the noise stream: offset = symbols already drawn (odd offsets too)
+    off = 12345
+    tail = m.modulate_awgn(bits, _Awgn(0.01, 4711, off, ctx)).to_host()
+    y, _ = pipeline.run(pipeline.Stage.modulate_awgn(ctx, bps, 0.01, 4711, offset=off), bits, chunk=bps * N * 5)
+    assert bits_equal(y, tail)
+    with pytest.raises(ap.AetherError, match="first stage"):
+        pipeline.run_chain([pipeline.Stage.fft(plan), mod], rand_c64(1, N))
+
+
+def _Awgn(power, seed, offset, ctx):
+    from aether_primitives_amd import noise
+    a = noise.new(ctx, power, seed); a.offset = offset
+    return a
