@@ -99,6 +99,8 @@ PROTOTYPES = {
     "aeth_host_unregister": (i32, [vp, vp]),
     "aeth_host_is_pinned": (i32, [vp, sz]),
     "aeth_vec_chain": (i32, [vp, vp, sz, vp, sz]),
+    "aeth_vec_fft": (i32, [vp, vp, sz, i32, i32, f32]),
+    "aeth_host_vec_fft": (i32, [vp, vp, sz, i32, i32, f32]),
     "aeth_stream_out_count": (sz, [vp, vp, sz]),
     "aeth_stream_host": (i32, [vp, vp, vp, sz, vp, sz, sz, vp]),
     "aeth_stream_chain_out_count": (sz, [vp, vp, sz, sz]),

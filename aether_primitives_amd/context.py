@@ -226,13 +226,11 @@ class DeviceVec:
     def vec_sub(self, other):                                     # vecops.rs:70
         o = self._other(other); check(self.ctx._lib.aeth_vec_sub(self.ctx.h, self._p(), self.n, o._p(), o.n)); return self
 
-    def vec_fft(self, scale):                                     # vecops.rs:74, :185-189 (fresh plan)
-        from .fft import HipFft
-        HipFft(self.ctx, self.n).ifwd(self, scale); return self
+    def vec_fft(self, scale):                                     # vecops.rs:74, :185-189 (the reference plans per call; the context caches)
+        check(self.ctx._lib.aeth_vec_fft(self.ctx.h, self._p(), self.n, +1, scale.kind, scale.x)); return self
 
     def vec_ifft(self, scale):                                    # vecops.rs:78, :191-196
-        from .fft import HipFft
-        HipFft(self.ctx, self.n).ibwd(self, scale); return self
+        check(self.ctx._lib.aeth_vec_fft(self.ctx.h, self._p(), self.n, -1, scale.kind, scale.x)); return self
 
     def vec_rfft(self, fft, scale):                               # vecops.rs:83, :198-202
         fft.ifwd(self, scale); return self
@@ -319,12 +317,10 @@ class HostVec:
         return self
 
     def vec_fft(self, scale):
-        from .fft import HipFft
-        HipFft(self.ctx, self.a.size).ifwd(self.a, scale); return self
+        check(self.ctx._lib.aeth_host_vec_fft(self.ctx.h, self._p(), self.a.size, +1, scale.kind, scale.x)); return self
 
     def vec_ifft(self, scale):
-        from .fft import HipFft
-        HipFft(self.ctx, self.a.size).ibwd(self.a, scale); return self
+        check(self.ctx._lib.aeth_host_vec_fft(self.ctx.h, self._p(), self.a.size, -1, scale.kind, scale.x)); return self
 
     def vec_rfft(self, fft, scale):
         fft.ifwd(self.a, scale); return self

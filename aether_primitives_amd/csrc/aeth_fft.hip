@@ -816,6 +816,65 @@ int aeth_fft_destroy(aeth_fft *p)
     return AETH_OK;
 }
 
+}  // extern "C"
+
+/* VecOps::vec_fft / vec_ifft (src/vecops.rs:184-196): `Cfft::with_len(self.len())` then ifwd / ibwd -- the reference plans
+ * on EVERY call ("planning + allocation every call").  Here the context keeps the plans these one-shot calls
+ * have built (the eight most recently used lengths; a plan is its twiddle tables and scratch), so the second vec_fft of a
+ * length costs what vec_rfft with a reused plan costs.  aeth_ctx_trim / aeth_ctx_destroy free them. */
+namespace {
+constexpr size_t kFftCacheMax = 8;
+struct FftCache { std::vector<aeth_fft *> plans; };
+
+int fft_cache_get(aeth_ctx *ctx, size_t len, aeth_fft **out)
+{
+    if (!ctx->fft_cache) {
+        ctx->fft_cache = new (std::nothrow) FftCache();
+        AETH_REQUIRE(ctx->fft_cache, AETH_E_NOMEM, "out of host memory");
+    }
+    auto &v = static_cast<FftCache *>(ctx->fft_cache)->plans;
+    for (size_t i = 0; i < v.size(); i++)
+        if (v[i]->len == len) { aeth_fft *p = v[i]; v.erase(v.begin() + (long)i); v.insert(v.begin(), p); *out = p; return AETH_OK; }
+    aeth_fft *p = nullptr;
+    int rc = aeth_fft_create(ctx, len, 1, &p); if (rc) return rc;
+    if (v.size() >= kFftCacheMax) { (void)aeth_fft_destroy(v.back()); v.pop_back(); }
+    v.insert(v.begin(), p);
+    *out = p;
+    return AETH_OK;
+}
+}  // namespace
+
+namespace aeth {
+void fft_cache_release(aeth_ctx *ctx)
+{
+    if (!ctx->fft_cache) return;
+    FftCache *c = static_cast<FftCache *>(ctx->fft_cache);
+    for (aeth_fft *p : c->plans) (void)aeth_fft_destroy(p);
+    delete c;
+    ctx->fft_cache = nullptr;
+}
+}  // namespace aeth
+
+extern "C" {
+
+int aeth_vec_fft(aeth_ctx *ctx, aeth_cf32 *x_dev, size_t n, int sign, int kind, float x)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    AETH_REQUIRE(n >= 1, AETH_E_ARG, "FFT length must be >= 1");
+    aeth_fft *p = nullptr;
+    int rc = fft_cache_get(ctx, n, &p); if (rc) return rc;
+    return aeth_fft_exec(p, x_dev, n, x_dev, 1, sign, kind, x);
+}
+
+int aeth_host_vec_fft(aeth_ctx *ctx, aeth_cf32 *x_host, size_t n, int sign, int kind, float x)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    AETH_REQUIRE(n >= 1, AETH_E_ARG, "FFT length must be >= 1");
+    aeth_fft *p = nullptr;
+    int rc = fft_cache_get(ctx, n, &p); if (rc) return rc;
+    return aeth_fft_exec_host(p, x_host, n, x_host, n, sign, kind, x);
+}
+
 size_t aeth_fft_len(const aeth_fft *p) { return p ? p->len : 0; }
 const char *aeth_fft_algorithm(const aeth_fft *p) { return p ? p->algo_name : ""; }
 

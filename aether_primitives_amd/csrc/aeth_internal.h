@@ -41,6 +41,8 @@ struct aeth_ctx {
     size_t stage_bytes[2] = {0, 0};
     // small host-slice calls: two pinned, device-visible bounce buffers (aeth::HostIO)
     void *bounce[2] = {nullptr, nullptr};
+    // plans of the one-shot vec_fft / vec_ifft (aeth_fft.hip: fft_cache_get), most recently used first
+    void *fft_cache = nullptr;
 };
 
 namespace aeth {
@@ -58,6 +60,8 @@ hipStream_t ctx_fir_lane(aeth_ctx *ctx, uintptr_t in_lo, uintptr_t in_hi, uintpt
 
 // ensure staging slot `i` holds >= bytes of device memory
 int ctx_stage(aeth_ctx *ctx, int i, size_t bytes);
+// frees the plans vec_fft / vec_ifft built for this context (aeth_ctx_destroy, aeth_ctx_trim)
+void fft_cache_release(aeth_ctx *ctx);
 
 // Buffers of one host-slice call (the literal trait call: host slice in, host slice out, synchronous).
 //   small (every buffer <= kZeroCopyMax): the context's two pinned, device-visible bounce buffers -- memcpy in, the kernel

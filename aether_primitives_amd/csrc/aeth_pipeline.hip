@@ -660,6 +660,7 @@ int aeth_ctx_trim(aeth_ctx *ctx)
     AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
     aeth::DeviceGuard g(ctx->device);
     AETH_HIP(hipStreamSynchronize(aeth::ctx_stream(ctx)));
+    aeth::fft_cache_release(ctx);
     aeth::pipe_release(ctx);
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) { AETH_HIP(hipFree(ctx->stage[i])); ctx->stage[i] = nullptr; ctx->stage_bytes[i] = 0; }

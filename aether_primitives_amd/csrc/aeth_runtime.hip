@@ -242,6 +242,7 @@ int aeth_ctx_destroy(aeth_ctx *ctx)
     if (!ctx) return AETH_OK;
     aeth::DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(aeth::ctx_stream(ctx));
+    aeth::fft_cache_release(ctx);
     overlap_release(ctx);
     aeth::pipe_release(ctx);
     for (int i = 0; i < 2; i++) {

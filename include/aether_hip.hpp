@@ -217,8 +217,9 @@ private:
     aeth_fft *h_ = nullptr;
 };
 
-inline DeviceVec &DeviceVec::vec_fft(Scale s) { HipFft f(*ctx_, n_); f.ifwd(*this, s); return *this; }
-inline DeviceVec &DeviceVec::vec_ifft(Scale s) { HipFft f(*ctx_, n_); f.ibwd(*this, s); return *this; }
+// the reference plans per call (vecops.rs:185-189); the context keeps the plans these calls built
+inline DeviceVec &DeviceVec::vec_fft(Scale s) { check(aeth_vec_fft(c(), p_, n_, HipFft::kFwdSign, s.kind, s.x)); return *this; }
+inline DeviceVec &DeviceVec::vec_ifft(Scale s) { check(aeth_vec_fft(c(), p_, n_, HipFft::kBwdSign, s.kind, s.x)); return *this; }
 inline DeviceVec &DeviceVec::vec_rfft(HipFft &fft, Scale s) { fft.ifwd(*this, s); return *this; }
 inline DeviceVec &DeviceVec::vec_rifft(HipFft &fft, Scale s) { fft.ibwd(*this, s); return *this; }
 
@@ -237,8 +238,8 @@ public:
     HostVec &vec_add(const std::vector<cf32> &o) { check(aeth_host_vec_add(c(), raw(p_), n_, raw(o.data()), o.size())); return *this; }
     HostVec &vec_sub(const std::vector<cf32> &o) { check(aeth_host_vec_sub(c(), raw(p_), n_, raw(o.data()), o.size())); return *this; }
     HostVec &vec_mutate(const std::function<void(cf32 &)> &f) { for (size_t i = 0; i < n_; i++) f(p_[i]); return *this; }
-    HostVec &vec_fft(Scale s) { HipFft f(*ctx_, n_); f.ifwd(p_, n_, s); return *this; }
-    HostVec &vec_ifft(Scale s) { HipFft f(*ctx_, n_); f.ibwd(p_, n_, s); return *this; }
+    HostVec &vec_fft(Scale s) { check(aeth_host_vec_fft(c(), raw(p_), n_, HipFft::kFwdSign, s.kind, s.x)); return *this; }
+    HostVec &vec_ifft(Scale s) { check(aeth_host_vec_fft(c(), raw(p_), n_, HipFft::kBwdSign, s.kind, s.x)); return *this; }
     HostVec &vec_rfft(Fft &fft, Scale s) { fft.ifwd(p_, n_, s); return *this; }
     HostVec &vec_rifft(Fft &fft, Scale s) { fft.ibwd(p_, n_, s); return *this; }
 

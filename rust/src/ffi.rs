@@ -142,6 +142,8 @@ extern "C" {
     pub fn aeth_host_register(ctx: *mut aeth_ctx, ptr: *mut c_void, bytes: usize) -> c_int;
     pub fn aeth_host_unregister(ctx: *mut aeth_ctx, ptr: *mut c_void) -> c_int;
     pub fn aeth_host_is_pinned(ptr: *const c_void, bytes: usize) -> c_int;
+    pub fn aeth_vec_fft(ctx: *mut aeth_ctx, x: *mut cf32, n: usize, sign: c_int, kind: c_int, x_scale: c_float) -> c_int;
+    pub fn aeth_host_vec_fft(ctx: *mut aeth_ctx, x: *mut cf32, n: usize, sign: c_int, kind: c_int, x_scale: c_float) -> c_int;
     pub fn aeth_vec_chain(ctx: *mut aeth_ctx, self_: *mut cf32, n: usize, steps: *const aeth_vec_step, n_steps: usize) -> c_int;
     pub fn aeth_stream_out_count(ctx: *mut aeth_ctx, op: *const aeth_stream_op, n_in: usize) -> usize;
     pub fn aeth_stream_host(ctx: *mut aeth_ctx, op: *const aeth_stream_op, inp: *const c_void, n_in: usize, out: *mut c_void,

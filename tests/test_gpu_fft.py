@@ -320,3 +320,27 @@ def test_fft_then_interpolate_in_one_call(ctx, n, batch, nb):
         h = one.to_host()
         assert wrote == Lo * batch and bits_equal(h[:Lo * batch], two.to_host())
         assert (h[Lo * batch:] == 5 - 5j).all() and bits_equal(src.to_host(), x)      # nothing past dst, input untouched
+
+
+def test_one_shot_vec_fft_reuses_the_contexts_plans(ctx, oracle):
+    """vec_fft / vec_ifft (vecops.rs:184-196) plan per call in the reference; here the context keeps the plans: results are
+    those of a fresh plan, more lengths than the cache holds still work, a trimmed context plans again, and the second
+    call of a length is much cheaper than the first"""
+    import time
+    for n in (100, 128, 2048, 6000, 17, 1000, 4096, 512, 960, 3600, 100, 2048):     # 10 distinct lengths > 8 cached, repeats
+        x = rand_c64(n, n)
+        got = ctx.vec(x).vec_fft(Scale.SN).to_host()
+        d = ctx.vec(x); HipFft(ctx, n).ifwd(d, Scale.SN)
+        assert bits_equal(got, d.to_host()), n
+        back = ctx.vec(got).vec_ifft(Scale.SN).to_host()
+        assert oracle.evm_db(back, x.astype(np.complex128)) <= -120
+        h = ap.HostVec(ctx, x.copy()); h.vec_fft(Scale.SN)
+        assert bits_equal(h.a, got), n
+    v = ctx.vec(rand_c64(1, 3000))
+    ctx.sync(); t0 = time.perf_counter(); v.vec_fft(Scale.NONE); ctx.sync(); first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(20): v.vec_fft(Scale.NONE)
+    ctx.sync(); later = (time.perf_counter() - t0) / 20
+    assert later < first / 3, (first, later)
+    ctx.trim()
+    assert bits_equal(ctx.vec(rand_c64(5, 128)).vec_fft(Scale.N).to_host(), ctx.vec(rand_c64(5, 128)).vec_fft(Scale.N).to_host())
