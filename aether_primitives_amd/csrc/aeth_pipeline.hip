@@ -9,10 +9,12 @@
 //     download       device slot   -> pinned pool element          HIP stream 2 (D2H copy engine)
 //     copy-out       pinned        -> caller slice                 host threads
 //
-// The reference's pipeline takes an arbitrary closure per stage (pipeline.rs:24-41 `add_stage<F: FnMut(O) -> U>`,
-// :123-137 `new`); a closure cannot cross the C ABI, so the compute stage is an op descriptor (aeth_stream_op): the
-// fused FIR, batched FFT frames, the correlator chain, correlate + demod (8 B in, 1-2 B out per sample) or FFT +
-// interpolate (1 sample in, n_between + 1 out) -- input and output chunks differ in element size and count per op.
+// The reference's pipeline takes an arbitrary closure per stage (src/pipeline.rs:24-41 `add_stage<F: FnMut(O) -> U>`,
+// :123-137 `new`); a closure cannot cross the C ABI, so the compute stage is an op descriptor (aeth_stream_op) or a
+// chain of up to eight of them (`add_stage` ... `add_stage`: intermediates stay on the device): the fused FIR (plain or
+// with its decimating store), batched FFT frames, the correlator chain, correlate + demod (8 B in, 1-2 B out per sample),
+// FFT + interpolate (1 sample in, n_between + 1 out), modulate + AWGN (bit bytes in, symbols out) -- input and output
+// chunks differ in element size and count per op.
 //
 // Slots are handed from stage to stage by events (device stages) and completion counters (host stages); the
 // calling thread only enqueues and polls.  A side whose caller memory is ALREADY page-locked -- it lies inside an
