@@ -823,7 +823,7 @@ int aeth_fft_destroy(aeth_fft *p)
  * have built (the eight most recently used lengths; a plan is its twiddle tables and scratch), so the second vec_fft of a
  * length costs what vec_rfft with a reused plan costs.  aeth_ctx_trim / aeth_ctx_destroy free them. */
 namespace {
-constexpr size_t kFftCacheMax = 8;
+constexpr size_t kFftCacheMax = 8, kFftCachePoints = (size_t)1 << 24;
 struct FftCache { std::vector<aeth_fft *> plans; };
 
 int fft_cache_get(aeth_ctx *ctx, size_t len, aeth_fft **out)
@@ -837,8 +837,15 @@ int fft_cache_get(aeth_ctx *ctx, size_t len, aeth_fft **out)
         if (v[i]->len == len) { aeth_fft *p = v[i]; v.erase(v.begin() + (long)i); v.insert(v.begin(), p); *out = p; return AETH_OK; }
     aeth_fft *p = nullptr;
     int rc = aeth_fft_create(ctx, len, 1, &p); if (rc) return rc;
-    if (v.size() >= kFftCacheMax) { (void)aeth_fft_destroy(v.back()); v.pop_back(); }
     v.insert(v.begin(), p);
+    // at most eight plans and 2^24 points of them in total (a plan's tables and scratch are a few times its length): the least
+    // recently used ones go first, the plan just built always stays
+    size_t total = 0;
+    for (aeth_fft *q : v) total += q->len;
+    while (v.size() > 1 && (v.size() > kFftCacheMax || total > kFftCachePoints)) {
+        total -= v.back()->len;
+        (void)aeth_fft_destroy(v.back()); v.pop_back();
+    }
     *out = p;
     return AETH_OK;
 }

@@ -199,7 +199,7 @@ AETH_API int aeth_fft_exec_interpolate(aeth_fft *plan, const aeth_cf32 *in_dev, 
                                        int compat_im, size_t *n_written);
 /* VecOps::vec_fft / vec_ifft (src/vecops.rs:184-196): in place on a whole slice with a plan of its length.  The reference
  * builds a fresh Cfft on every call; the context keeps the plans these calls have built (the eight most recently used
- * lengths; aeth_ctx_trim frees them), so a repeated length plans once.  sign: AETH_SIGN_REF_FWD for vec_fft, _BWD for vec_ifft. */
+ * lengths, 2^24 points in total at most; aeth_ctx_trim frees them), so a repeated length plans once.  sign: AETH_SIGN_REF_FWD for vec_fft, _BWD for vec_ifft. */
 AETH_API int aeth_vec_fft(aeth_ctx *ctx, aeth_cf32 *x_dev, size_t n, int sign, int scale_kind, float x);
 AETH_API int aeth_host_vec_fft(aeth_ctx *ctx, aeth_cf32 *x_host, size_t n, int sign, int scale_kind, float x);
 /* host slices, one frame per call: the literal trait methods. out may equal in. */
