@@ -24,6 +24,7 @@ struct aeth_ctx {
     // results are those of one in-order stream.
     hipStream_t stream_aux = nullptr;
     hipEvent_t ev_pre[2] = {nullptr, nullptr};   // [lane] recorded on that lane right before its latest FIR launch
+    bool ev_pre_empty[2] = {false, false};       // ... unless that launch started on an idle context: nothing was in front of it
     hipEvent_t ev_aux_done = nullptr;
     bool overlap = false;          // feature switch (off for borrowed streams)
     bool stream_shared = false;    // aeth_ctx_stream() handed the main stream to code this library does not see: the
