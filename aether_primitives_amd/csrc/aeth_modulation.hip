@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kPairs = 2;          // modulate_awgn_kernel: sample pairs per lane
 
 struct Table4 { float2 s[4]; };
 
@@ -154,14 +155,29 @@ __global__ __launch_bounds__(kBlock) void modulate_awgn_kernel(const uint8_t *__
                                                                size_t nsym, Table4 t, float scale, uint64_t seed,
                                                                uint64_t offset, int wide)
 {
-    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    // the table in LDS: one indexed 8-byte read per symbol where pick() spends two compares and six selects (the kernel
+    // is issue-bound on the generator's arithmetic: 70.7 -> 66 us per 2^25 symbols)
+    __shared__ float2 tab[4];
+    if (threadIdx.x < 4) tab[threadIdx.x] = t.s[threadIdx.x];
+    __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPairs; k++) {                               // kPairs pairs per lane, a grid's width apart (aeth_noise.hip)
+    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;
     const size_t i0 = 2 * p;
     if (i0 >= nsym) return;
     const bool two = i0 + 1 < nsym;
     unsigned idx0, idx1 = 0;
-    if constexpr (BPS == 1) { idx0 = bits[i0] & 1u; if (two) idx1 = bits[i0 + 1] & 1u; }
+    if ((wide & 2) && two) {                                        // the pair's bit bytes in one aligned load
+        if constexpr (BPS == 1) {
+            const unsigned v = *reinterpret_cast<const uint16_t *>(bits + i0);
+            idx0 = v & 1u; idx1 = (v >> 8) & 1u;
+        } else {
+            const unsigned v = *reinterpret_cast<const uint32_t *>(bits + 2 * i0);
+            idx0 = qpsk_index(v, v >> 8); idx1 = qpsk_index(v >> 16, v >> 24);
+        }
+    } else if constexpr (BPS == 1) { idx0 = bits[i0] & 1u; if (two) idx1 = bits[i0 + 1] & 1u; }
     else { idx0 = qpsk_index(bits[2 * i0], bits[2 * i0 + 1]); if (two) idx1 = qpsk_index(bits[2 * i0 + 2], bits[2 * i0 + 3]); }
-    float2 a = pick(t, idx0), b = pick(t, idx1);
+    float2 a = tab[idx0], b = tab[idx1];
     float n0r, n0i, n1r = 0.f, n1i = 0.f;
     if ((offset & 1) == 0) {
         uint32_t w[4];
@@ -177,8 +193,9 @@ __global__ __launch_bounds__(kBlock) void modulate_awgn_kernel(const uint8_t *__
     a.y = a.y + (n0i * scale) * scale;
     b.x = b.x + (n1r * scale) * scale;
     b.y = b.y + (n1i * scale) * scale;
-    if (wide && two) aeth::nt_store<NT>(reinterpret_cast<float4 *>(out + i0), make_float4(a.x, a.y, b.x, b.y));
+    if ((wide & 1) && two) aeth::nt_store<NT>(reinterpret_cast<float4 *>(out + i0), make_float4(a.x, a.y, b.x, b.y));
     else { out[i0] = a; if (two) out[i0 + 1] = b; }
+  }
 }
 
 int fill_table_n(TableN &t, int bps, const aeth_cf32 *host)
@@ -266,12 +283,12 @@ int aeth_modulate_awgn(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps
     const float scale = sqrtf(power);                               // noise.rs:35
     const size_t pairs = (n_out + 1) / 2;
     const bool nt = aeth::streams_past_cache(n_out * sizeof(float2));
-    const int wide = aeth::aligned16(out) ? 1 : 0;
+    const int wide = (aeth::aligned16(out) ? 1 : 0) | (((uintptr_t)bits % (size_t)(2 * bps)) == 0 ? 2 : 0);
 #define AETH_MA(B)                                                                                                              \
     do {                                                                                                                        \
-        if (nt) hipLaunchKernelGGL((modulate_awgn_kernel<B, true>), dim3(grid_for(pairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx), \
+        if (nt) hipLaunchKernelGGL((modulate_awgn_kernel<B, true>), dim3(grid_for((pairs + kPairs - 1) / kPairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx), \
                                    bits, (float2 *)out, n_out, t, scale, seed, offset, wide);                                  \
-        else hipLaunchKernelGGL((modulate_awgn_kernel<B, false>), dim3(grid_for(pairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx),   \
+        else hipLaunchKernelGGL((modulate_awgn_kernel<B, false>), dim3(grid_for((pairs + kPairs - 1) / kPairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx),   \
                                 bits, (float2 *)out, n_out, t, scale, seed, offset, wide);                                     \
     } while (0)
     if (bps == 1) AETH_MA(1); else AETH_MA(2);

@@ -8,7 +8,10 @@
 //                                                  amplitude is proportional to `power`)
 // The stream itself is the build's own counter-based generator (aeth_rng.h): the reference's
 // StdRng/ziggurat sequence cannot be reproduced.  Compiled with -ffp-contract=off.
-// HBM-bound at 16 B/sample; one lane per PAIR of samples (one Philox call, one 16-byte access).
+// One lane per PAIR of samples (one Philox call, one 16-byte access), kPairs pairs per lane a grid's width apart: the
+// generator is issue-bound (about 130 vector instructions per pair), and a wave that ends on its only store holds its
+// slot for the store's latency with nothing to issue -- with a second pair behind it the slot keeps computing
+// (tools/rng_lab.hip: 55 -> 50 us per 2^25 samples; more than two measured no better).
 #include "aeth_internal.h"
 
 #define AETH_RNG_FN __host__ __device__ static inline
@@ -17,12 +20,16 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kPairs = 2;
+inline unsigned pair_grid(size_t pairs) { return (unsigned)((pairs + (size_t)kBlock * kPairs - 1) / ((size_t)kBlock * kPairs)); }
 
 template <bool NT>
 __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__ x, size_t n, float scale,
                                                             uint64_t seed, uint64_t offset, int wide)
 {
-    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;       // pair index
+#pragma unroll
+  for (int k = 0; k < kPairs; k++) {
+    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;       // pair index
     const size_t i0 = 2 * p;
     if (i0 >= n) return;
     // stream position of sample i is offset + i; an odd offset shifts the pairing, so draw per sample then
@@ -56,6 +63,7 @@ __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__
             x[i0 + 1] = b;
         }
     }
+  }
 }
 
 // Awgn::fill / Awgn::iter (noise.rs:61-84): target[i] = next() = (N(0,1) as f32 * scale, ...), scaled ONCE
@@ -63,7 +71,9 @@ template <bool NT>
 __global__ __launch_bounds__(kBlock) void awgn_fill_kernel(float2 *__restrict__ x, size_t n, float scale,
                                                            uint64_t seed, uint64_t offset, int wide)
 {
-    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < kPairs; k++) {
+    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;
     const size_t i0 = 2 * p;
     if (i0 >= n) return;
     float n0r, n0i, n1r = 0.f, n1i = 0.f;
@@ -83,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void awgn_fill_kernel(float2 *__restrict__ 
         x[i0] = make_float2(n0r * scale, n0i * scale);
         if (i0 + 1 < n) x[i0 + 1] = make_float2(n1r * scale, n1i * scale);
     }
+  }
 }
 
 // the generator's integer stage on its own: out[i] = Philox4x32-R(counter = in[i][0..3], key = in[i][4..5])
@@ -111,7 +122,7 @@ int aeth_awgn_fill(aeth_ctx *ctx, aeth_cf32 *target, size_t n, float power, uint
     aeth::DeviceGuard dev_guard(ctx->device);
     const size_t pairs = (n + 1) / 2;
     auto kern = aeth::streams_past_cache(n * sizeof(float2)) ? awgn_fill_kernel<true> : awgn_fill_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
+    hipLaunchKernelGGL(kern, dim3(pair_grid(pairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
                        reinterpret_cast<float2 *>(target), n, scale, seed, offset, aeth::aligned16(target) ? 1 : 0);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
@@ -146,7 +157,7 @@ int aeth_awgn_apply(aeth_ctx *ctx, aeth_cf32 *signal, size_t n, float power, uin
     aeth::DeviceGuard dev_guard(ctx->device);
     const size_t pairs = (n + 1) / 2;
     auto kern = aeth::streams_past_cache(2 * n * sizeof(float2)) ? awgn_apply_kernel<true> : awgn_apply_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
+    hipLaunchKernelGGL(kern, dim3(pair_grid(pairs)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
                        reinterpret_cast<float2 *>(signal), n, scale, seed, offset, aeth::aligned16(signal) ? 1 : 0);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
