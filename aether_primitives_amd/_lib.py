@@ -129,6 +129,7 @@ PROTOTYPES = {
     "aeth_awgn_fill": (i32, [vp, vp, sz, f32, C.c_uint64, C.c_uint64]),
     "aeth_rng_philox4x32_10": (i32, [vp, vp, sz, vp]),
     "aeth_rng_philox4x32": (i32, [vp, vp, sz, i32, vp]),
+    "aeth_rng_normal_pairs": (i32, [vp, vp, sz, vp]),
 }
 
 _lib = None

@@ -107,6 +107,17 @@ __global__ __launch_bounds__(kBlock) void philox_kernel(const uint32_t *__restri
     out[4 * i] = w[0]; out[4 * i + 1] = w[1]; out[4 * i + 2] = w[2]; out[4 * i + 3] = w[3];
 }
 
+// the generator's floating-point stage on its own: out[i] = the complex normal of the word pair (ab[i][0], ab[i][1])
+__global__ __launch_bounds__(kBlock) void normal_pairs_kernel(const uint2 *__restrict__ ab, float2 *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint2 w = ab[i];
+    float2 z;
+    aeth_rng_normal_pair(w.x, w.y, &z.x, &z.y);
+    out[i] = z;
+}
+
 }  // namespace
 
 extern "C" {
@@ -137,6 +148,19 @@ int aeth_rng_philox4x32(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, in
     aeth::DeviceGuard dev_guard(ctx->device);
     auto kern = rounds == 7 ? philox_kernel<7> : philox_kernel<10>;
     hipLaunchKernelGGL(kern, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx), ctr_key_dev, out_dev, n);
+    AETH_HIP(hipGetLastError());
+    return AETH_OK;
+}
+
+int aeth_rng_normal_pairs(aeth_ctx *ctx, const uint32_t *ab_dev, size_t n, aeth_cf32 *out_dev)
+{
+    AETH_REQUIRE(ctx, AETH_E_ARG, "ctx is null");
+    if (n == 0) return AETH_OK;
+    AETH_REQUIRE(ab_dev && out_dev, AETH_E_ARG, "null pointer");
+    AETH_REQUIRE(aeth::aligned8(ab_dev) && aeth::aligned8(out_dev), AETH_E_ALIGN, "pointers not 8-byte aligned");
+    aeth::DeviceGuard dev_guard(ctx->device);
+    hipLaunchKernelGGL(normal_pairs_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
+                       reinterpret_cast<const uint2 *>(ab_dev), reinterpret_cast<float2 *>(out_dev), n);
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }

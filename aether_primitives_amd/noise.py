@@ -62,6 +62,25 @@ def philox4x32(ctx, counters, keys, rounds=7):
     return out
 
 
+def normal_pairs(ctx, a, b):
+    """The generator's floating-point stage on the device: word pairs (a[i], b[i]) uint32 -> complex64 standard normals."""
+    import ctypes as C
+    ab = np.ascontiguousarray(np.stack([np.asarray(a, np.uint32), np.asarray(b, np.uint32)], axis=1))
+    n = ab.shape[0]
+    lib = _lib.load()
+    din, dout = C.c_void_p(), C.c_void_p()
+    check(lib.aeth_dev_alloc(ctx.h, max(ab.nbytes, 8), C.byref(din))); check(lib.aeth_dev_alloc(ctx.h, max(8 * n, 8), C.byref(dout)))
+    try:
+        out = np.empty(n, np.complex64)
+        if n:
+            check(lib.aeth_upload(ctx.h, din, ab.ctypes.data_as(C.c_void_p), ab.nbytes))
+            check(lib.aeth_rng_normal_pairs(ctx.h, din, n, dout))
+            check(lib.aeth_download(ctx.h, out.ctypes.data_as(C.c_void_p), dout, out.nbytes))
+    finally:
+        lib.aeth_dev_free(ctx.h, din); lib.aeth_dev_free(ctx.h, dout)
+    return out
+
+
 def generator(ctx):                          # noise.rs:8-11
     return Awgn(ctx, 1.0, DEFAULT_RNG_SEED)
 

@@ -453,6 +453,13 @@ AETH_API int aeth_awgn_fill(aeth_ctx *ctx, aeth_cf32 *target_dev, size_t n, floa
  * known-answer vectors of both are in tests/golden/philox4x32_{7,10}_kat.json.  Device pointers, n x 6 and n x 4 words. */
 AETH_API int aeth_rng_philox4x32(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, int rounds, uint32_t *out_dev);
 AETH_API int aeth_rng_philox4x32_10(aeth_ctx *ctx, const uint32_t *ctr_key_dev, size_t n, uint32_t *out_dev);
+/* The generator's floating-point stage by itself (replaces rand_distr::Normal, src/noise.rs:3,39-43): out[i] = the
+ * complex standard normal the generator makes of the 32-bit word pair (ab[i][0], ab[i][1]) -- radius from the first
+ * word (u = ((a >> 8) | 1) / 2^24, r = sqrt(-2 ln u)), angle from the second.  Exists so that the stage can be pinned
+ * over its WHOLE radius argument (all 2^24 values of a >> 8: the device takes r from v_rsq_f32 plus one correcting
+ * step, the oracle from sqrtf) instead of on the samples a stream happens to draw; tests/test_gpu_modulation.py does
+ * that.  Device pointers, n x 2 words in, n samples out. */
+AETH_API int aeth_rng_normal_pairs(aeth_ctx *ctx, const uint32_t *ab_dev, size_t n, aeth_cf32 *out_dev);
 
 #ifdef __cplusplus
 }

@@ -594,6 +594,12 @@ void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, ui
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32(ctr, key, 10, out); }
 
+/* the Box-Muller stage on explicit word pairs: out[i] = normal of (ab[2i], ab[2i+1]) */
+void orc_rng_normal_pairs(const uint32_t *ab, size_t n, orc_cf32 *out)
+{
+    for (size_t i = 0; i < n; i++) aeth_rng_normal_pair(ab[2 * i], ab[2 * i + 1], &out[i].re, &out[i].im);
+}
+
 /* Awgn::fill (noise.rs:61-65): push next() until the capacity is reached; next() scales once (noise.rs:39-43) */
 void orc_awgn_fill(orc_cf32 *target, size_t n, float power, uint64_t seed, uint64_t offset)
 {

@@ -137,6 +137,7 @@ void orc_awgn_apply(orc_cf32 *signal, size_t n, float power, uint64_t seed, uint
 void orc_awgn_fill(orc_cf32 *target, size_t n, float power, uint64_t seed, uint64_t offset);   /* noise.rs:61-65 */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);   /* rounds: 7 (the generator's) or 10 */
+void orc_rng_normal_pairs(const uint32_t *ab, size_t n, orc_cf32 *out);   /* the Box-Muller stage on explicit word pairs */
 
 /* ---- deterministic synthetic input (the build's own generator) ---------- */
 /* complex normal, unit power (sigma = 1/sqrt(2) per component), splitmix64 +

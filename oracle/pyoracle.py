@@ -112,6 +112,7 @@ def lib():
             "orc_awgn_fill": (None, [vp, sz, f32, C.c_uint64, C.c_uint64]),
             "orc_philox4x32_10": (None, [vp, vp, vp]),
             "orc_philox4x32": (None, [vp, vp, i32, vp]),
+            "orc_rng_normal_pairs": (None, [vp, C.c_size_t, vp]),
             "orc_time_shape": (f64, [i32, sz, sz, i32]),
             "orc_synth_cnormal": (None, [C.c_uint64, vp, sz]),
             "orc_synth_lowpass_taps": (None, [sz, f64, vp]),
@@ -352,6 +353,13 @@ def time_shape(op, n, b=0, reps=1000):
 def philox4x32(counter, key, rounds):
     c = np.ascontiguousarray(counter, np.uint32); k = np.ascontiguousarray(key, np.uint32); o = np.empty(4, np.uint32)
     lib().orc_philox4x32(c.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p), int(rounds), o.ctypes.data_as(C.c_void_p)); return o
+
+
+def rng_normal_pairs(a, b):
+    """the generator's Box-Muller stage on explicit word pairs (a[i], b[i])"""
+    ab = np.ascontiguousarray(np.stack([np.asarray(a, np.uint32), np.asarray(b, np.uint32)], axis=1))
+    out = np.empty(ab.shape[0], np.complex64)
+    lib().orc_rng_normal_pairs(ab.ctypes.data_as(C.c_void_p), ab.shape[0], _p(out)); return out
 
 
 def awgn_apply(signal, power, seed=815, offset=0):

@@ -186,6 +186,7 @@ extern "C" {
     pub fn aeth_awgn_fill(ctx: *mut aeth_ctx, target: *mut cf32, n: usize, power: c_float, seed: u64, offset: u64) -> c_int;
     pub fn aeth_rng_philox4x32_10(ctx: *mut aeth_ctx, ctr_key: *const u32, n: usize, out: *mut u32) -> c_int;
     pub fn aeth_rng_philox4x32(ctx: *mut aeth_ctx, ctr_key: *const u32, n: usize, rounds: c_int, out: *mut u32) -> c_int;
+    pub fn aeth_rng_normal_pairs(ctx: *mut aeth_ctx, ab: *const u32, n: usize, out: *mut aeth_cf32) -> c_int;
     pub fn aeth_host_downsample(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void,
                                 n_dst: usize, elem_size: usize) -> c_int;
     pub fn aeth_downsample_release(ctx: *mut aeth_ctx, src: *const c_void, n_src: usize, dst: *mut c_void, n_dst: usize,

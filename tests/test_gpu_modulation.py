@@ -166,6 +166,30 @@ def test_philox_known_answers_on_the_device(ctx, oracle, rounds):
         noise.philox4x32(ctx, ctr[:1], key[:1], 8)
 
 
+def test_box_muller_stage_over_its_whole_radius_argument(ctx, oracle):
+    """The generator's floating-point stage on explicit words (aeth_rng_normal_pairs): every one of the 2^24 values
+    the radius can be drawn from -- the device takes r = sqrt(-2 ln u) from v_rsq_f32 plus one correcting step, the
+    oracle from sqrtf: they must agree on ALL of them, not on the ones a stream happens to hit -- each with its own
+    angle word; then the corners of the angle (0, +-pi/2, pi, the words around them) and empty input."""
+    rng = np.random.default_rng(3)
+    step = 1 << 22
+    for k0 in range(0, 1 << 24, step):
+        a = (np.arange(k0, k0 + step, dtype=np.uint64) << 8).astype(np.uint32) | rng.integers(0, 256, step, dtype=np.uint32)
+        b = rng.integers(0, 2 ** 32, step, dtype=np.uint64).astype(np.uint32)
+        got = noise.normal_pairs(ctx, a, b)
+        assert np.isfinite(got.view(np.float32)).all()
+        assert bits_equal(got, oracle.rng_normal_pairs(a, b)), f"radius words {k0:#x}.."
+    corners = np.array([0, 1, 0x3fffffff, 0x40000000, 0x40000001, 0x7fffffff, 0x80000000, 0x80000001, 0xbfffffff,
+                        0xc0000000, 0xc0000001, 0xffffffff], np.uint32)
+    a = np.full(corners.size, 0x12345678, np.uint32)
+    got = noise.normal_pairs(ctx, a, corners)
+    assert bits_equal(got, oracle.rng_normal_pairs(a, corners))
+    r = np.sqrt(-2 * np.log(((0x12345678 >> 8) | 1) / 2.0 ** 24))
+    th = np.pi * corners.astype(np.int32).astype(np.float64) / 2.0 ** 31
+    assert np.abs(got - r * np.exp(1j * th)).max() < 5e-6
+    assert noise.normal_pairs(ctx, np.zeros(0, np.uint32), np.zeros(0, np.uint32)).size == 0
+
+
 @pytest.mark.parametrize("n,offset", [(1, 0), (2, 1), (7, 0), (4097, 3), (1 << 20, 1 << 33)])
 def test_awgn_fill_bit_exact(ctx, oracle, n, offset):
     """Awgn::fill / iter (noise.rs:61-84): next() scaled once; stream positions continue across calls"""
