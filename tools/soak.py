@@ -94,6 +94,15 @@ while time.time() - t0 < secs:
         compat = bool(rng.integers(2))
         got = m.demod_naive(tx, compat=compat).to_host()
         if not (got == orc.demod_naive(ref, bps, compat=compat)).all(): print(f"demod mismatch bps={bps} nsym={nsym}"); sys.exit(1)
+        # the fused form and the fill, at a random stream position (odd ones take the per-sample draw) and alignment
+        off = int(rng.integers(0, 1 << 40)); lead = int(rng.integers(0, 2))
+        g = noise.new(ctx, 0.04, seed); g.offset = off
+        buf = ctx.empty(nsym + lead)
+        fused = m.modulate_awgn(modulation.DeviceBits(ctx, bits.size, bits), g, out=buf.slice(lead, lead + nsym))
+        if not bits_equal(fused.to_host(), orc.awgn_apply(orc.modulate(bits, bps), 0.04, seed=seed, offset=off)): print(f"modulate_awgn mismatch bps={bps} nsym={nsym} off={off} lead={lead}"); sys.exit(1)
+        g2 = noise.new(ctx, 0.04, seed); g2.offset = off
+        g2.fill(buf.slice(lead, lead + nsym))
+        if not bits_equal(buf.slice(lead, lead + nsym).to_host(), orc.awgn_fill(nsym, 0.04, seed, off)): print(f"awgn fill mismatch nsym={nsym} off={off} lead={lead}"); sys.exit(1)
     elif kind == 5:                                          # round 4: a random chain of links in one pass (aeth_vec_chain), bit-exact
         n = int(rng.integers(1, 1 << 20)); nl = int(rng.integers(1, 20))
         ops = [np.complex64(2) + rand_c64(int(rng.integers(1 << 30)), n + 3) for _ in range(3)]
