@@ -161,41 +161,41 @@ __global__ __launch_bounds__(kBlock) void modulate_awgn_kernel(const uint8_t *__
     if (threadIdx.x < 4) tab[threadIdx.x] = t.s[threadIdx.x];
     __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kPairs; k++) {                               // kPairs pairs per lane, a grid's width apart (aeth_noise.hip)
-    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;
-    const size_t i0 = 2 * p;
-    if (i0 >= nsym) return;
-    const bool two = i0 + 1 < nsym;
-    unsigned idx0, idx1 = 0;
-    if ((wide & 2) && two) {                                        // the pair's bit bytes in one aligned load
-        if constexpr (BPS == 1) {
-            const unsigned v = *reinterpret_cast<const uint16_t *>(bits + i0);
-            idx0 = v & 1u; idx1 = (v >> 8) & 1u;
+    for (int k = 0; k < kPairs; k++) {                               // kPairs pairs per lane, a grid's width apart (aeth_noise.hip)
+        const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;
+        const size_t i0 = 2 * p;
+        if (i0 >= nsym) return;
+        const bool two = i0 + 1 < nsym;
+        unsigned idx0, idx1 = 0;
+        if ((wide & 2) && two) {                                        // the pair's bit bytes in one aligned load
+            if constexpr (BPS == 1) {
+                const unsigned v = *reinterpret_cast<const uint16_t *>(bits + i0);
+                idx0 = v & 1u; idx1 = (v >> 8) & 1u;
+            } else {
+                const unsigned v = *reinterpret_cast<const uint32_t *>(bits + 2 * i0);
+                idx0 = qpsk_index(v, v >> 8); idx1 = qpsk_index(v >> 16, v >> 24);
+            }
+        } else if constexpr (BPS == 1) { idx0 = bits[i0] & 1u; if (two) idx1 = bits[i0 + 1] & 1u; }
+        else { idx0 = qpsk_index(bits[2 * i0], bits[2 * i0 + 1]); if (two) idx1 = qpsk_index(bits[2 * i0 + 2], bits[2 * i0 + 3]); }
+        float2 a = tab[idx0], b = tab[idx1];
+        float n0r, n0i, n1r = 0.f, n1i = 0.f;
+        if ((offset & 1) == 0) {
+            uint32_t w[4];
+            const uint64_t call = (offset + i0) >> 1;
+            aeth_rng_draw(call, seed, w);
+            aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
+            aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
         } else {
-            const unsigned v = *reinterpret_cast<const uint32_t *>(bits + 2 * i0);
-            idx0 = qpsk_index(v, v >> 8); idx1 = qpsk_index(v >> 16, v >> 24);
+            aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
+            if (two) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
         }
-    } else if constexpr (BPS == 1) { idx0 = bits[i0] & 1u; if (two) idx1 = bits[i0 + 1] & 1u; }
-    else { idx0 = qpsk_index(bits[2 * i0], bits[2 * i0 + 1]); if (two) idx1 = qpsk_index(bits[2 * i0 + 2], bits[2 * i0 + 3]); }
-    float2 a = tab[idx0], b = tab[idx1];
-    float n0r, n0i, n1r = 0.f, n1i = 0.f;
-    if ((offset & 1) == 0) {
-        uint32_t w[4];
-        const uint64_t call = (offset + i0) >> 1;
-        aeth_rng_draw(call, seed, w);
-        aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
-        aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
-    } else {
-        aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
-        if (two) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
+        a.x = a.x + (n0r * scale) * scale;          // noise.rs:41 then :58
+        a.y = a.y + (n0i * scale) * scale;
+        b.x = b.x + (n1r * scale) * scale;
+        b.y = b.y + (n1i * scale) * scale;
+        if ((wide & 1) && two) aeth::nt_store<NT>(reinterpret_cast<float4 *>(out + i0), make_float4(a.x, a.y, b.x, b.y));
+        else { out[i0] = a; if (two) out[i0 + 1] = b; }
     }
-    a.x = a.x + (n0r * scale) * scale;          // noise.rs:41 then :58
-    a.y = a.y + (n0i * scale) * scale;
-    b.x = b.x + (n1r * scale) * scale;
-    b.y = b.y + (n1i * scale) * scale;
-    if ((wide & 1) && two) aeth::nt_store<NT>(reinterpret_cast<float4 *>(out + i0), make_float4(a.x, a.y, b.x, b.y));
-    else { out[i0] = a; if (two) out[i0 + 1] = b; }
-  }
 }
 
 int fill_table_n(TableN &t, int bps, const aeth_cf32 *host)

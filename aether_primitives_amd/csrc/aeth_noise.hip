@@ -28,42 +28,42 @@ __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__
                                                             uint64_t seed, uint64_t offset, int wide)
 {
 #pragma unroll
-  for (int k = 0; k < kPairs; k++) {
-    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;       // pair index
-    const size_t i0 = 2 * p;
-    if (i0 >= n) return;
-    // stream position of sample i is offset + i; an odd offset shifts the pairing, so draw per sample then
-    float n0r, n0i, n1r = 0.f, n1i = 0.f;
-    if ((offset & 1) == 0) {
-        uint32_t w[4];
-        const uint64_t call = (offset + i0) >> 1;
-        aeth_rng_draw(call, seed, w);
-        aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
-        aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
-    } else {
-        aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
-        if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
-    }
-    if (wide && i0 + 1 < n) {
-        float4 v = aeth::nt_load<NT>(reinterpret_cast<float4 *>(x + i0));
-        v.x = v.x + (n0r * scale) * scale;          // noise.rs:41 then :58
-        v.y = v.y + (n0i * scale) * scale;
-        v.z = v.z + (n1r * scale) * scale;
-        v.w = v.w + (n1i * scale) * scale;
-        aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), v);
-    } else {
-        float2 a = x[i0];
-        a.x = a.x + (n0r * scale) * scale;
-        a.y = a.y + (n0i * scale) * scale;
-        x[i0] = a;
-        if (i0 + 1 < n) {
-            float2 b = x[i0 + 1];
-            b.x = b.x + (n1r * scale) * scale;
-            b.y = b.y + (n1i * scale) * scale;
-            x[i0 + 1] = b;
+    for (int k = 0; k < kPairs; k++) {
+        const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;       // pair index
+        const size_t i0 = 2 * p;
+        if (i0 >= n) return;
+        // stream position of sample i is offset + i; an odd offset shifts the pairing, so draw per sample then
+        float n0r, n0i, n1r = 0.f, n1i = 0.f;
+        if ((offset & 1) == 0) {
+            uint32_t w[4];
+            const uint64_t call = (offset + i0) >> 1;
+            aeth_rng_draw(call, seed, w);
+            aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
+            aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
+        } else {
+            aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
+            if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
+        }
+        if (wide && i0 + 1 < n) {
+            float4 v = aeth::nt_load<NT>(reinterpret_cast<float4 *>(x + i0));
+            v.x = v.x + (n0r * scale) * scale;          // noise.rs:41 then :58
+            v.y = v.y + (n0i * scale) * scale;
+            v.z = v.z + (n1r * scale) * scale;
+            v.w = v.w + (n1i * scale) * scale;
+            aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), v);
+        } else {
+            float2 a = x[i0];
+            a.x = a.x + (n0r * scale) * scale;
+            a.y = a.y + (n0i * scale) * scale;
+            x[i0] = a;
+            if (i0 + 1 < n) {
+                float2 b = x[i0 + 1];
+                b.x = b.x + (n1r * scale) * scale;
+                b.y = b.y + (n1i * scale) * scale;
+                x[i0 + 1] = b;
+            }
         }
     }
-  }
 }
 
 // Awgn::fill / Awgn::iter (noise.rs:61-84): target[i] = next() = (N(0,1) as f32 * scale, ...), scaled ONCE
@@ -72,28 +72,28 @@ __global__ __launch_bounds__(kBlock) void awgn_fill_kernel(float2 *__restrict__ 
                                                            uint64_t seed, uint64_t offset, int wide)
 {
 #pragma unroll
-  for (int k = 0; k < kPairs; k++) {
-    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;
-    const size_t i0 = 2 * p;
-    if (i0 >= n) return;
-    float n0r, n0i, n1r = 0.f, n1i = 0.f;
-    if ((offset & 1) == 0) {
-        uint32_t w[4];
-        const uint64_t call = (offset + i0) >> 1;
-        aeth_rng_draw(call, seed, w);
-        aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
-        aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
-    } else {
-        aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
-        if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
+    for (int k = 0; k < kPairs; k++) {
+        const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;
+        const size_t i0 = 2 * p;
+        if (i0 >= n) return;
+        float n0r, n0i, n1r = 0.f, n1i = 0.f;
+        if ((offset & 1) == 0) {
+            uint32_t w[4];
+            const uint64_t call = (offset + i0) >> 1;
+            aeth_rng_draw(call, seed, w);
+            aeth_rng_normal_pair(w[0], w[1], &n0r, &n0i);
+            aeth_rng_normal_pair(w[2], w[3], &n1r, &n1i);
+        } else {
+            aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
+            if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
+        }
+        if (wide && i0 + 1 < n) {
+            aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), make_float4(n0r * scale, n0i * scale, n1r * scale, n1i * scale));
+        } else {
+            x[i0] = make_float2(n0r * scale, n0i * scale);
+            if (i0 + 1 < n) x[i0 + 1] = make_float2(n1r * scale, n1i * scale);
+        }
     }
-    if (wide && i0 + 1 < n) {
-        aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), make_float4(n0r * scale, n0i * scale, n1r * scale, n1i * scale));
-    } else {
-        x[i0] = make_float2(n0r * scale, n0i * scale);
-        if (i0 + 1 < n) x[i0 + 1] = make_float2(n1r * scale, n1i * scale);
-    }
-  }
 }
 
 // the generator's integer stage on its own: out[i] = Philox4x32-R(counter = in[i][0..3], key = in[i][4..5])
