@@ -51,7 +51,7 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     // AETH_FIR_GRID_FIRST for the first launch of a chain / a lone launch on a context with the lane on.
     if (ctx->overlap && !ctx->stream_shared && C::WG == 128) {
         const int num = ctx->last_chained ? aeth::tuning_int("AETH_FIR_GRID_CHAINED", 12) : aeth::tuning_int("AETH_FIR_GRID_FIRST", 16);
-        if (num > 0 && num < 16) cap = cap * num / 16;
+        if (num > 0 && num != 16) cap = cap * num / 16;      // above 16: more workgroups than fit at once (they queue for slots)
     }
     int grid = (int)(ngroups < cap ? ngroups : cap);
     if (grid < 1) grid = 1;

@@ -77,7 +77,9 @@ enum { AETH_SIGN_REF_FWD = +1, AETH_SIGN_REF_BWD = -1 };
  * csrc/aeth_internal.h, lab_int):
  *   AETH_FIR_GRID_FIRST    sixteenths of the resident grid for a fused-FIR launch that starts a chain or runs alone
  *                          with the overlap lane on (default 16)
- *   AETH_FIR_GRID_CHAINED  the same for a launch that runs beside its predecessor (default 12)
+ *   AETH_FIR_GRID_CHAINED  the same for a launch that runs beside its predecessor (default 12); values above 16
+ *                          oversubscribe: the workgroups without a slot start as earlier ones finish (measured
+ *                          20 / 24 / 32: within noise of 12, profiles/r04_k20_trace.txt)
  *   AETH_FIR_SPREAD        0 / 1: force the burst / spread form of the next-window prefetch (default: spread for a
  *                          lone launch, burst beside another)
  *   AETH_NT                0 / 1: force plain / non-temporal accesses on streamed operands (default: by size)

@@ -40,6 +40,15 @@ configs = [
     ("2q first12 ch13", True, 12, 13, False),
     ("2q first14 ch12", True, 14, 12, False),
     ("1q", False, 16, 16, False),
+    # oversubscribed grids: more workgroups than fit at once -- the ones without a slot start as their predecessor's
+    # finish, so the LAST launch of a chain can fill the whole machine while it drains
+    ("2q first16 ch16", True, 16, 16, False),
+    ("2q first16 ch20", True, 16, 20, False),
+    ("2q first16 ch24", True, 16, 24, False),
+    ("2q first16 ch32", True, 16, 32, False),
+    ("2q first24 ch24", True, 24, 24, False),
+    ("2q first32 ch32", True, 32, 32, False),
+    ("2q first16 ch48", True, 16, 48, False),
 ]
 if len(sys.argv) > 3:
     configs = [c for c in configs if any(a in c[0] for a in sys.argv[3:])]
