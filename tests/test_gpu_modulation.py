@@ -190,6 +190,18 @@ def test_box_muller_stage_over_its_whole_radius_argument(ctx, oracle):
     assert noise.normal_pairs(ctx, np.zeros(0, np.uint32), np.zeros(0, np.uint32)).size == 0
 
 
+def test_generator_fixture_on_the_device(ctx):
+    """tests/golden/generator_v3.json: the committed samples of the build's own generator, drawn by the device"""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "generator_v3.json")))
+    for s in fx["streams"]:
+        g = noise.new(ctx, s["power"], s["seed"]); g.offset = s["offset"]
+        got = g.fill(ctx.empty(s["n"])).to_host().view(np.uint32)
+        assert [f"{v:08x}" for v in got] == s["fill"], (s["seed"], s["offset"])
+    a = np.array([int(x, 16) for x in fx["pairs"]["a"]], np.uint32); b = np.array([int(x, 16) for x in fx["pairs"]["b"]], np.uint32)
+    assert [f"{v:08x}" for v in noise.normal_pairs(ctx, a, b).view(np.uint32)] == fx["pairs"]["normal"]
+
+
 @pytest.mark.parametrize("n,offset", [(1, 0), (2, 1), (7, 0), (4097, 3), (1 << 20, 1 << 33)])
 def test_awgn_fill_bit_exact(ctx, oracle, n, offset):
     """Awgn::fill / iter (noise.rs:61-84): next() scaled once; stream positions continue across calls"""

@@ -281,3 +281,16 @@ def test_awgn_fill_scales_once_apply_twice(oracle):
     assert np.allclose(a, f * np.float32(0.5), rtol=1e-6)           # sqrt(0.25) once more
     one = oracle.awgn_fill(1000, 1.0, 815, 0)
     assert np.array_equal(oracle.awgn_apply(z, 1.0, 815, 0).view(np.uint32), one.view(np.uint32))
+
+
+def test_generator_fixture_is_what_the_oracle_draws(oracle):
+    """tests/golden/generator_v3.json (the build's own generator pinned as data, written by make_generator_fixture.py):
+    the oracle must still draw exactly these samples -- a change to the generator's definition has to come with a
+    new fixture, it cannot slip into oracle and kernel together unnoticed."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "generator_v3.json")))
+    for s in fx["streams"]:
+        got = oracle.awgn_fill(s["n"], s["power"], s["seed"], s["offset"]).view(np.uint32)
+        assert [f"{v:08x}" for v in got] == s["fill"], (s["seed"], s["offset"])
+    a = np.array([int(x, 16) for x in fx["pairs"]["a"]], np.uint32); b = np.array([int(x, 16) for x in fx["pairs"]["b"]], np.uint32)
+    assert [f"{v:08x}" for v in oracle.rng_normal_pairs(a, b).view(np.uint32)] == fx["pairs"]["normal"]
