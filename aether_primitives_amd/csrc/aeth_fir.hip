@@ -40,7 +40,11 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
 {
     long long ngroups = (a.nblocks + C::F - 1) / C::F;
     // persistent grid = what is resident at once: the kernel's ~230 VGPRs allow 2 waves per SIMD, 8 per CU
-    long long cap = (long long)ctx->num_cus * 8 / (C::WG / 64);
+    // (the lab's 8-points-per-lane build of N = 2048 needs half the registers: 16 waves per CU)
+    constexpr bool kLab8 = (C::N == 2048 && C::P == 8);
+    [[maybe_unused]] const bool lab8_four = kLab8 && aeth::lab_int("AETH_DEMOD_P8", 0) == 4;    // 128 registers forced: 4 workgroups per CU
+    const int kWavesPerCu = kLab8 ? (lab8_four ? 16 : 12) : 8;                   // 146 registers: 3 waves per SIMD
+    long long cap = (long long)ctx->num_cus * kWavesPerCu / (C::WG / 64);
     // A launch that runs BESIDE its predecessor on the overlap lane takes three of the four 128-lane workgroups a CU
     // holds: a full grid keeps every wave slot until its last round, so its successor could only overlap that tail;
     // with a slot per CU free the two run side by side from the start.  tools/fir_lab, two queues, grids 704 ... 800
@@ -70,13 +74,16 @@ int launch_fmi(aeth_ctx *ctx, const FmiArgs &a, hipStream_t stream)
     // launch in tools/fir_lab, A/B in one process); the other variants of aeth_fir_kernel.h measured null or negative
     // ... and N = 2048 (the configuration it was measured on) keeps its exchange image XOR-swizzled instead of padded:
     // no two-way conflict on the contiguous reads, transform-only time 39.8 -> 34.8 us, launch 54.8 -> 53.4 us
-    constexpr int VAR = (C::F == 1) ? (V_PRIO | (C::N == 2048 ? V_XOR : 0)) : 0;
+    constexpr int VAR = (C::F == 1) ? (V_PRIO | ((C::N == 2048 && C::P == 16) ? V_XOR : 0)) : 0;
     if constexpr (C::F == 1) {
         if (b.bits) {                                       // hard demodulation instead of the sample store
             // the decision's mode is a template parameter (aeth_fir_kernel.h: demod_block): BPSK, QPSK with a
             // separable table, QPSK with any other table -- nothing about it is tested per sample
 #define AETH_DM(DMV)                                                                                                                \
             do {                                                                                                                    \
+                if constexpr (kLab8) {                                                                                              \
+                    if (lab8_four) { hipLaunchKernelGGL((fmi_kernel<C, SCALED, 4, true, false, VAR | V_DEMOD | (DMV)>), dim3(grid), dim3(C::WG), 0, stream, b); break; } \
+                }                                                                                                                   \
                 if (nt) hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, true, false, VAR | V_DEMOD | (DMV)>), dim3(grid), dim3(C::WG), 0, stream, b); \
                 else hipLaunchKernelGGL((fmi_kernel<C, SCALED, 1, false, false, VAR | V_DEMOD | (DMV)>), dim3(grid), dim3(C::WG), 0, stream, b);   \
             } while (0)
@@ -123,6 +130,17 @@ int dispatch_fmi(aeth_ctx *ctx, size_t fft_len, const FmiArgs &a, hipStream_t st
     if (!stream) stream = aeth::ctx_stream(ctx);
     aeth::DeviceGuard dev_guard(ctx->device);
     const bool scaled = a.chirp != nullptr || !(a.s_fwd == 1.0f && a.s_bwd == 1.0f);
+#if AETH_LAB
+    // lab (make LAB=1): the demodulating build of N = 2048 with 256 lanes x 8 points (radices 8.8.8.4: three exchanges
+    // per transform, half the registers, four waves per SIMD) -- the kernel is bound by its transform time at two
+    // waves per SIMD; does twice the occupancy buy more than the extra exchange costs?
+    if (fft_len == 2048 && a.bits && !a.chirp && aeth::lab_int("AETH_DEMOD_P8", 0)) {
+        FmiArgs b8 = a;
+        b8.twL = nullptr;                                    // the plan's lane table is laid out for 16 points per lane
+        using C8 = Cfg<2048, 8, 8, 8, 8, 4>;
+        return scaled ? launch_fmi<C8, true>(ctx, b8, stream) : launch_fmi<C8, false>(ctx, b8, stream);
+    }
+#endif
 #define AETH_BODY(NN)                                                            \
     return scaled ? launch_fmi<typename CfgFor<NN>::type, true>(ctx, a, stream)  \
                   : launch_fmi<typename CfgFor<NN>::type, false>(ctx, a, stream)
