@@ -12,6 +12,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kPairs = 2;          // modulate_awgn_kernel: sample pairs per lane
+constexpr int kItems = 4;          // modulate_kernel / demod_kernel, vector form: 4-byte bit groups per lane
 
 struct Table4 { float2 s[4]; };
 
@@ -50,25 +51,42 @@ __device__ __forceinline__ unsigned nearest(float2 v, const Table4 &t, int ncand
 
 // Four input bytes and 16-byte stores per lane where the alignment allows (VEC): these
 // kernels move 10 B per symbol and are store- (modulate) or load-bound (demod).
+// item index of lane `tid`, slot k: a wave owns kItems * 64 consecutive items and takes them 64 at a time, so every
+// access of a wave is one contiguous run and the kItems loads of a lane are in flight together
+__device__ __forceinline__ size_t item_of(int k)
+{
+    return ((size_t)blockIdx.x * kBlock + (threadIdx.x & ~63u)) * kItems + (size_t)k * 64 + (threadIdx.x & 63u);
+}
+
 template <int BPS, bool VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void modulate_kernel(const uint8_t *__restrict__ bits, float2 *__restrict__ out,
                                                           size_t nsym, Table4 t)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if constexpr (VEC) {
-        constexpr int SPL = 4 / BPS;                     // symbols per lane: 4 bytes of bits
-        const size_t s0 = i * SPL;
-        if (s0 >= nsym) return;
-        const uchar4 b = aeth::nt_load<NT>(reinterpret_cast<const uchar4 *>(bits) + i);
-        if constexpr (BPS == 2) {
-            const float2 a = pick(t, qpsk_index(b.x, b.y)), c = pick(t, qpsk_index(b.z, b.w));
-            aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + i, make_float4(a.x, a.y, c.x, c.y));
-        } else {
-            const float2 a = pick(t, b.x & 1u), c = pick(t, b.y & 1u), d = pick(t, b.z & 1u), e = pick(t, b.w & 1u);   // modulation.rs:9-12
-            aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + 2 * i, make_float4(a.x, a.y, c.x, c.y));
-            aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + 2 * i + 1, make_float4(d.x, d.y, e.x, e.y));
+        // kItems items (4 bytes of bits each) per lane, all loads first: a lane with one 4-byte load in flight leaves the
+        // kernel bound by the latency of that load, not by its 10 B per symbol
+        constexpr int SPL = 4 / BPS;                     // symbols per item
+        uchar4 b[kItems];
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {
+            const size_t i = item_of(k);
+            if (i * SPL < nsym) b[k] = aeth::nt_load<NT>(reinterpret_cast<const uchar4 *>(bits) + i);
+        }
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {
+            const size_t i = item_of(k);
+            if (i * SPL >= nsym) return;
+            if constexpr (BPS == 2) {
+                const float2 a = pick(t, qpsk_index(b[k].x, b[k].y)), c = pick(t, qpsk_index(b[k].z, b[k].w));
+                aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + i, make_float4(a.x, a.y, c.x, c.y));
+            } else {
+                const float2 a = pick(t, b[k].x & 1u), c = pick(t, b[k].y & 1u), d = pick(t, b[k].z & 1u), e = pick(t, b[k].w & 1u);   // modulation.rs:9-12
+                aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + 2 * i, make_float4(a.x, a.y, c.x, c.y));
+                aeth::nt_store<NT>(reinterpret_cast<float4 *>(out) + 2 * i + 1, make_float4(d.x, d.y, e.x, e.y));
+            }
         }
     } else {
+        const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
         if (i >= nsym) return;
         unsigned idx;
         if constexpr (BPS == 1) idx = bits[i] & 1u;
@@ -81,24 +99,36 @@ template <int BPS, bool VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void demod_kernel(const float2 *__restrict__ sym, uint8_t *__restrict__ bits,
                                                        size_t nsym, Table4 t, int compat)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     constexpr int NC = (BPS == 1) ? 2 : 4;              // trait default scans BITS_PER_SYMBOL*2 candidates (:135)
     auto hi = [&](unsigned best) { return (uint8_t)(compat ? (best & 2u) : ((best >> 1) & 1u)); };   // modulation.rs:54
     if constexpr (VEC) {
         constexpr int SPL = 4 / BPS;
-        if (i * SPL >= nsym) return;
-        if constexpr (BPS == 2) {
-            const float4 v = aeth::nt_load<NT>(reinterpret_cast<const float4 *>(sym) + i);
-            const unsigned a = nearest(make_float2(v.x, v.y), t, NC), c = nearest(make_float2(v.z, v.w), t, NC);
-            aeth::nt_store<NT>(reinterpret_cast<uchar4 *>(bits) + i, make_uchar4((uint8_t)(a & 1u), hi(a), (uint8_t)(c & 1u), hi(c)));
-        } else {
-            const float4 v = aeth::nt_load<NT>(reinterpret_cast<const float4 *>(sym) + 2 * i), w = aeth::nt_load<NT>(reinterpret_cast<const float4 *>(sym) + 2 * i + 1);
-            reinterpret_cast<uchar4 *>(bits)[i] = make_uchar4((uint8_t)(nearest(make_float2(v.x, v.y), t, NC) & 1u),
-                                                              (uint8_t)(nearest(make_float2(v.z, v.w), t, NC) & 1u),
-                                                              (uint8_t)(nearest(make_float2(w.x, w.y), t, NC) & 1u),
-                                                              (uint8_t)(nearest(make_float2(w.z, w.w), t, NC) & 1u));   // :143
+        constexpr int LD = (BPS == 2) ? 1 : 2;          // 16-byte loads per item
+        float4 v[kItems][LD];
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {              // kItems items per lane, all loads first (see modulate_kernel)
+            const size_t i = item_of(k);
+            if (i * SPL < nsym) {
+#pragma unroll
+                for (int j = 0; j < LD; j++) v[k][j] = aeth::nt_load<NT>(reinterpret_cast<const float4 *>(sym) + LD * i + j);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {
+            const size_t i = item_of(k);
+            if (i * SPL >= nsym) return;
+            if constexpr (BPS == 2) {
+                const unsigned a = nearest(make_float2(v[k][0].x, v[k][0].y), t, NC), c = nearest(make_float2(v[k][0].z, v[k][0].w), t, NC);
+                aeth::nt_store<NT>(reinterpret_cast<uchar4 *>(bits) + i, make_uchar4((uint8_t)(a & 1u), hi(a), (uint8_t)(c & 1u), hi(c)));
+            } else {
+                reinterpret_cast<uchar4 *>(bits)[i] = make_uchar4((uint8_t)(nearest(make_float2(v[k][0].x, v[k][0].y), t, NC) & 1u),
+                                                                  (uint8_t)(nearest(make_float2(v[k][0].z, v[k][0].w), t, NC) & 1u),
+                                                                  (uint8_t)(nearest(make_float2(v[k][LD - 1].x, v[k][LD - 1].y), t, NC) & 1u),
+                                                                  (uint8_t)(nearest(make_float2(v[k][LD - 1].z, v[k][LD - 1].w), t, NC) & 1u));   // :143
+            }
         }
     } else {
+        const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
         if (i >= nsym) return;
         const unsigned best = nearest(sym[i], t, NC);
         if constexpr (BPS == 1) bits[i] = (uint8_t)(best & 1u);
@@ -251,7 +281,7 @@ int aeth_modulate(aeth_ctx *ctx, const uint8_t *bits, size_t nbits, int bps, con
     AETH_REQUIRE(aeth::aligned8(out) && ((uintptr_t)bits % (size_t)bps) == 0, AETH_E_ALIGN, "pointer alignment");
     const size_t spl = 4 / (size_t)bps;
     const bool vec = aeth::aligned16(out) && ((uintptr_t)bits % 4) == 0 && (n_out % spl) == 0;
-    const dim3 gv(grid_for(n_out / spl)), gs(grid_for(n_out)), b(kBlock);
+    const dim3 gv(grid_for((n_out / spl + kItems - 1) / kItems)), gs(grid_for(n_out)), b(kBlock);
     const bool nt = aeth::streams_past_cache(n_out * sizeof(float2));
 #define AETH_MOD(B, V, G)                                                                                                 \
     do {                                                                                                                  \
@@ -324,7 +354,7 @@ int aeth_demod_naive(aeth_ctx *ctx, const aeth_cf32 *sym, size_t nsym, int bps, 
     AETH_REQUIRE(aeth::aligned8(sym) && ((uintptr_t)bits % (size_t)bps) == 0, AETH_E_ALIGN, "pointer alignment");
     const size_t spl = 4 / (size_t)bps;
     const bool vec = aeth::aligned16(sym) && ((uintptr_t)bits % 4) == 0 && (nsym % spl) == 0;
-    const dim3 gv(grid_for(nsym / spl)), gs(grid_for(nsym)), b(kBlock);
+    const dim3 gv(grid_for((nsym / spl + kItems - 1) / kItems)), gs(grid_for(nsym)), b(kBlock);
     const bool nt = aeth::streams_past_cache(nsym * sizeof(float2));
 #define AETH_DEM(B, V, G)                                                                                                         \
     do {                                                                                                                          \
