@@ -162,18 +162,33 @@ int launch_mul_frames(aeth_ctx *ctx, aeth_cf32 *frames, size_t frame_len, size_t
 }
 
 // ---- mirror: swap(x, x+mid), mid = len/2, per frame (vecops.rs:157-161) --------
-template <typename V, bool NT>
+// K items per lane (a wave owns K * 64 consecutive items, every access of a wave contiguous, all loads first): ONE
+// long frame -- two streams half a vector apart -- gains from four (93 -> 86 us for 2^25 samples), many short frames
+// lose (frames of 2048: 83 -> 87 us), so the launch picks K by the batch
+template <typename V, bool NT, int kMirrorItems>
 __global__ __launch_bounds__(kBlock) void mirror_kernel(V *__restrict__ x, size_t frame_stride_v, size_t mid_v,
                                                         size_t batch)
 {
-    // items = batch * mid_v, item -> (frame, j)
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= batch * mid_v) return;
-    size_t f = i / mid_v, j = i - f * mid_v;
-    V *p = x + f * frame_stride_v + j;
-    V lo = aeth::nt_load<NT>(p), hi = aeth::nt_load<NT>(p + mid_v);
-    aeth::nt_store<NT>(p, hi);
-    aeth::nt_store<NT>(p + mid_v, lo);
+    // items = batch * mid_v, item -> (frame, j); kMirrorItems items per lane, a wave's accesses contiguous, loads first
+    const size_t i0 = ((size_t)blockIdx.x * kBlock + (threadIdx.x & ~63u)) * kMirrorItems + (threadIdx.x & 63u);
+    V lo[kMirrorItems], hi[kMirrorItems];
+    V *p[kMirrorItems];
+#pragma unroll
+    for (int k = 0; k < kMirrorItems; k++) {
+        const size_t i = i0 + (size_t)k * 64;
+        if (i < batch * mid_v) {
+            size_t f = i / mid_v, j = i - f * mid_v;
+            p[k] = x + f * frame_stride_v + j;
+            lo[k] = aeth::nt_load<NT>(p[k]); hi[k] = aeth::nt_load<NT>(p[k] + mid_v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMirrorItems; k++) {
+        const size_t i = i0 + (size_t)k * 64;
+        if (i >= batch * mid_v) return;
+        aeth::nt_store<NT>(p[k], hi[k]);
+        aeth::nt_store<NT>(p[k] + mid_v, lo[k]);
+    }
 }
 
 int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch)
@@ -184,16 +199,22 @@ int launch_mirror(aeth_ctx *ctx, aeth_cf32 *self, size_t frame_len, size_t batch
     float2 *x = reinterpret_cast<float2 *>(self);
     const bool vec = aeth::aligned16(x) && (mid % 2 == 0) && (frame_len % 2 == 0);
     const bool nt = aeth::streams_past_cache(2 * batch * frame_len * sizeof(float2));
+    const bool four = batch == 1 && mid >= ((size_t)1 << 16);
+#define AETH_MIRROR(VV, KK, TOTAL, ...)                                                                                          \
+    do {                                                                                                                         \
+        auto k = nt ? mirror_kernel<VV, true, KK> : mirror_kernel<VV, false, KK>;                                                \
+        hipLaunchKernelGGL(k, dim3(grid_for(ctx, ((TOTAL) + (KK) - 1) / (KK))), dim3(kBlock), 0, aeth::ctx_stream(ctx), __VA_ARGS__); \
+    } while (0)
     if (vec) {
-        size_t total = batch * (mid / 2);
-        auto k = nt ? mirror_kernel<float4, true> : mirror_kernel<float4, false>;
-        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, aeth::ctx_stream(ctx),
-                           reinterpret_cast<float4 *>(x), frame_len / 2, mid / 2, batch);
+        const size_t total = batch * (mid / 2);
+        if (four) AETH_MIRROR(float4, 4, total, reinterpret_cast<float4 *>(x), frame_len / 2, mid / 2, batch);
+        else AETH_MIRROR(float4, 1, total, reinterpret_cast<float4 *>(x), frame_len / 2, mid / 2, batch);
     } else {
-        size_t total = batch * mid;
-        auto k = nt ? mirror_kernel<float2, true> : mirror_kernel<float2, false>;
-        hipLaunchKernelGGL(k, dim3(grid_for(ctx, total)), dim3(kBlock), 0, aeth::ctx_stream(ctx), x, frame_len, mid, batch);
+        const size_t total = batch * mid;
+        if (four) AETH_MIRROR(float2, 4, total, x, frame_len, mid, batch);
+        else AETH_MIRROR(float2, 1, total, x, frame_len, mid, batch);
     }
+#undef AETH_MIRROR
     AETH_HIP(hipGetLastError());
     return AETH_OK;
 }
