@@ -186,28 +186,33 @@ __global__ __launch_bounds__(kBlock) void modulate_awgn_kernel(const uint8_t *__
                                                                uint64_t offset, int wide)
 {
     // the table in LDS: one indexed 8-byte read per symbol where pick() spends two compares and six selects (the kernel
-    // is issue-bound on the generator's arithmetic: 70.7 -> 66 us per 2^25 symbols)
+    // is issue-bound on the generator's arithmetic: 70.7 -> 61.5 us per 2^25 symbols)
     __shared__ float2 tab[4];
     if (threadIdx.x < 4) tab[threadIdx.x] = t.s[threadIdx.x];
     __syncthreads();
+    // The bit bytes of ALL of the lane's pairs are requested first and looked at last: the noise does not depend on them,
+    // so their latency rides under the generator's arithmetic (it used to be waited for at the top of every pair)
+    unsigned v[kPairs];
 #pragma unroll
     for (int k = 0; k < kPairs; k++) {                               // kPairs pairs per lane, a grid's width apart (aeth_noise.hip)
-        const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;
-        const size_t i0 = 2 * p;
+        const size_t i0 = 2 * ((size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock);
+        v[k] = 0;
+        if (i0 >= nsym) break;
+        const bool two = i0 + 1 < nsym;
+        if ((wide & 2) && two) {                                        // the pair's bit bytes in one aligned load
+            if constexpr (BPS == 1) v[k] = *reinterpret_cast<const uint16_t *>(bits + i0);
+            else v[k] = *reinterpret_cast<const uint32_t *>(bits + 2 * i0);
+        } else if constexpr (BPS == 1) { v[k] = bits[i0]; if (two) v[k] |= (unsigned)bits[i0 + 1] << 8; }
+        else {
+            v[k] = bits[2 * i0] | ((unsigned)bits[2 * i0 + 1] << 8);
+            if (two) v[k] |= ((unsigned)bits[2 * i0 + 2] << 16) | ((unsigned)bits[2 * i0 + 3] << 24);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPairs; k++) {
+        const size_t i0 = 2 * ((size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock);
         if (i0 >= nsym) return;
         const bool two = i0 + 1 < nsym;
-        unsigned idx0, idx1 = 0;
-        if ((wide & 2) && two) {                                        // the pair's bit bytes in one aligned load
-            if constexpr (BPS == 1) {
-                const unsigned v = *reinterpret_cast<const uint16_t *>(bits + i0);
-                idx0 = v & 1u; idx1 = (v >> 8) & 1u;
-            } else {
-                const unsigned v = *reinterpret_cast<const uint32_t *>(bits + 2 * i0);
-                idx0 = qpsk_index(v, v >> 8); idx1 = qpsk_index(v >> 16, v >> 24);
-            }
-        } else if constexpr (BPS == 1) { idx0 = bits[i0] & 1u; if (two) idx1 = bits[i0 + 1] & 1u; }
-        else { idx0 = qpsk_index(bits[2 * i0], bits[2 * i0 + 1]); if (two) idx1 = qpsk_index(bits[2 * i0 + 2], bits[2 * i0 + 3]); }
-        float2 a = tab[idx0], b = tab[idx1];
         float n0r, n0i, n1r = 0.f, n1i = 0.f;
         if ((offset & 1) == 0) {
             uint32_t w[4];
@@ -219,6 +224,10 @@ __global__ __launch_bounds__(kBlock) void modulate_awgn_kernel(const uint8_t *__
             aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
             if (two) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
         }
+        unsigned idx0, idx1;
+        if constexpr (BPS == 1) { idx0 = v[k] & 1u; idx1 = (v[k] >> 8) & 1u; }
+        else { idx0 = qpsk_index(v[k], v[k] >> 8); idx1 = qpsk_index(v[k] >> 16, v[k] >> 24); }
+        float2 a = tab[idx0], b = tab[idx1];
         a.x = a.x + (n0r * scale) * scale;          // noise.rs:41 then :58
         a.y = a.y + (n0i * scale) * scale;
         b.x = b.x + (n1r * scale) * scale;
