@@ -27,6 +27,21 @@ template <bool NT>
 __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__ x, size_t n, float scale,
                                                             uint64_t seed, uint64_t offset, int wide)
 {
+    // the samples of ALL of the lane's pairs are requested first and used last: the noise does not depend on them, so
+    // their latency rides under the generator's arithmetic instead of being waited for behind it
+    float4 xv[kPairs];
+#pragma unroll
+    for (int k = 0; k < kPairs; k++) {
+        const size_t i0 = 2 * ((size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock);
+        xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 >= n) break;
+        if (wide && i0 + 1 < n) xv[k] = aeth::nt_load<NT>(reinterpret_cast<float4 *>(x + i0));
+        else {
+            const float2 a = x[i0];
+            xv[k].x = a.x; xv[k].y = a.y;
+            if (i0 + 1 < n) { const float2 b = x[i0 + 1]; xv[k].z = b.x; xv[k].w = b.y; }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < kPairs; k++) {
         const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x + (size_t)k * gridDim.x * kBlock;       // pair index
@@ -44,24 +59,15 @@ __global__ __launch_bounds__(kBlock) void awgn_apply_kernel(float2 *__restrict__
             aeth_rng_cnormal(seed, offset + i0, &n0r, &n0i);
             if (i0 + 1 < n) aeth_rng_cnormal(seed, offset + i0 + 1, &n1r, &n1i);
         }
-        if (wide && i0 + 1 < n) {
-            float4 v = aeth::nt_load<NT>(reinterpret_cast<float4 *>(x + i0));
-            v.x = v.x + (n0r * scale) * scale;          // noise.rs:41 then :58
-            v.y = v.y + (n0i * scale) * scale;
-            v.z = v.z + (n1r * scale) * scale;
-            v.w = v.w + (n1i * scale) * scale;
-            aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), v);
-        } else {
-            float2 a = x[i0];
-            a.x = a.x + (n0r * scale) * scale;
-            a.y = a.y + (n0i * scale) * scale;
-            x[i0] = a;
-            if (i0 + 1 < n) {
-                float2 b = x[i0 + 1];
-                b.x = b.x + (n1r * scale) * scale;
-                b.y = b.y + (n1i * scale) * scale;
-                x[i0 + 1] = b;
-            }
+        float4 v = xv[k];
+        v.x = v.x + (n0r * scale) * scale;          // noise.rs:41 then :58
+        v.y = v.y + (n0i * scale) * scale;
+        v.z = v.z + (n1r * scale) * scale;
+        v.w = v.w + (n1i * scale) * scale;
+        if (wide && i0 + 1 < n) aeth::nt_store<NT>(reinterpret_cast<float4 *>(x + i0), v);
+        else {
+            x[i0] = make_float2(v.x, v.y);
+            if (i0 + 1 < n) x[i0 + 1] = make_float2(v.z, v.w);
         }
     }
 }
