@@ -233,9 +233,19 @@ def side_workload(args):
         ctxs = [ctx] + [ap.Context(ranks.local_rank) for _ in range(nq - 1)]
         plans = [ap.HipFft(c, N, max_batch=n // N) for c in ctxs]
         bufs = [(ctxs[i % nq].vec(synth_stream(815 + i, n)), ctxs[i % nq].empty(n)) for i in range(4)]
+        # f.fwd(a, b, Scale.SN); f.ifwd(a, Scale.SN) (benches.rs:305-306,352-353) as the two C-ABI calls they are, argument
+        # tuples built once: the host side of a step is two ctypes calls and nothing else (the interpreter is not the product)
+        from aether_primitives_amd._lib import check as _check
+        from aether_primitives_amd.fft import SIGN_REF_FWD
+        _fx = plans[0]._lib.aeth_fft_exec
+        _c2 = []
+        for i in range(4):
+            a, b = bufs[i]; f = plans[i % nq]
+            _c2.append(((f.h, a._p(), a.n, b._p(), a.n // N, SIGN_REF_FWD, Scale.SN.kind, Scale.SN.x),
+                        (f.h, a._p(), a.n, a._p(), a.n // N, SIGN_REF_FWD, Scale.SN.kind, Scale.SN.x)))
         def step(i):
-            a, b = bufs[i % 4]; f = plans[(i % 4) % nq]
-            f.fwd(a, b, Scale.SN); f.ifwd(a, Scale.SN)          # benches.rs:305-306,352-353
+            fw, iw = _c2[i % 4]
+            _check(_fx(*fw)); _check(_fx(*iw))
 
         class _All:
             def sync(self_):
