@@ -190,3 +190,45 @@ def test_fourstep_largest_lengths(ctx, oracle, logn):
         assert bits_equal(got[:n], d.to_host())
         e = ctx.vec(y); f.ifwd(e, Scale.SN)
         assert bits_equal(got[n:], e.to_host())
+
+
+def test_c4_channel_at_baseline_size(ctx, oracle):
+    """One channel of BASELINE config 4 at its full size (4096 frames of 2048: 8.4 M QPSK symbols, noise power 0.01):
+    the two fused calls bench.py makes -- modulate_awgn, correlate_demod -- against (i) the four separate device calls,
+    bit for bit (symbols and decided bits), (ii) the oracle's chain on the transmit side bit for bit (8.4 M noisy
+    symbols: table lookup + the generator + the reference's double scaling), (iii) the oracle's receive chain: its FFT
+    rounds differently from the device's, so a decision may differ only where the oracle's own distances to the two
+    candidates are within rounding of each other -- and at this noise level none should."""
+    from aether_primitives_amd import modulation, noise
+    N, frames = 2048, 4096
+    n = N * frames
+    bits = np.random.default_rng(815).integers(0, 2, 2 * n, dtype=np.uint8)
+    q = modulation.qpsk(ctx)
+    dbits = modulation.DeviceBits(ctx, 2 * n, bits)
+    f = HipFft(ctx, N, max_batch=frames)
+    ref = np.zeros(N, np.complex64)
+    ref[:4] = np.conj(np.array([-1 + 1j, 0, 1 - 1j, 1 - 1j], np.complex64))       # benches.rs:394-405
+    sig = ctx.vec(ref)
+    tx = q.modulate_awgn(dbits, noise.new(ctx, 0.01, 815))
+    rx = q.correlate_demod(f, tx, sig).to_host()
+    # (i) the separate calls on the device
+    tx2 = q.modulate(dbits); noise.new(ctx, 0.01, 815).apply(tx2)
+    assert bits_equal(tx.to_host(), tx2.to_host())
+    f.mul_chain(tx2, sig)
+    assert (rx == q.demod_naive(tx2).to_host()).all()
+    # (ii) transmit side against the oracle
+    txo = oracle.awgn_apply(oracle.modulate(bits, 2), 0.01, seed=815)
+    assert bits_equal(tx.to_host(), txo)
+    # (iii) receive side against the oracle
+    yo = oracle.correlate_frames(ref, txo)
+    want = oracle.demod_naive(yo, 2, compat=True)
+    bad = np.flatnonzero(rx != want)
+    if bad.size:
+        sym = np.unique(bad // 2)
+        tab = np.array([1 + 1j, -1 + 1j, 1 - 1j, -1 - 1j], np.complex64)
+        d = np.abs(yo[sym, None] - tab[None, :]) ** 2
+        d.sort(axis=1)
+        assert sym.size <= 8 and ((d[:, 1] - d[:, 0]) <= 1e-4 * d[:, 1]).all(), (sym.size, d[:4])
+    # size-independent: the same bits again at another stream position decode to the same decisions only by chance
+    tx3 = q.modulate_awgn(dbits, noise.new(ctx, 0.01, 816))
+    assert not bits_equal(tx3.to_host()[:4096], txo[:4096])
