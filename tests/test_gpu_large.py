@@ -232,3 +232,34 @@ def test_c4_channel_at_baseline_size(ctx, oracle):
     # size-independent: the same bits again at another stream position decode to the same decisions only by chance
     tx3 = q.modulate_awgn(dbits, noise.new(ctx, 0.01, 816))
     assert not bits_equal(tx3.to_host()[:4096], txo[:4096])
+
+
+def test_c5_job_at_baseline_size(ctx, oracle):
+    """BASELINE config 5 at its full size on one GPU (512 frames of 65536 samples, forward FFT Scale::SN, then
+    sampling::interpolate with n_between = 9: 335 M output samples): the one call bench.py makes against the two trait-level
+    calls, bit for bit over the whole output (compared 64 frames at a time); two frames -- the first and the last --
+    against the oracle: the transform within -120 dB of the f64 transform, the interpolation of the device's spectrum bit
+    for bit."""
+    n, frames, nb = 65536, 512, 9
+    Lo = n + (n - 1) * nb
+    pat = rand_c64(815, P)
+    pd = ctx.vec(pat)
+    x = tiled(ctx, pd, n * frames)                       # frame f = pattern[(f * n) % P ...]: 64 distinct frames, repeated
+    x.slice(0, n).vec_scale(0.5)                         # ... and the first and last frame made different from their copies
+    x.slice(n * (frames - 1), n * frames).vec_conj()
+    f = HipFft(ctx, n, max_batch=frames)
+    one = ctx.empty(Lo * frames)
+    assert f.rfft_interpolate(x, one, nb, Scale.SN) == Lo * frames
+    spec = ctx.empty(n * frames); spec.vec_clone(x); f.ifwd(spec, Scale.SN)
+    two = ctx.empty(Lo * frames)
+    sampling.interpolate(ctx, spec, two, nb, frame_len=n)
+    step = 64
+    for f0 in range(0, frames, step):
+        a = one.slice(Lo * f0, Lo * (f0 + step)).to_host(); b = two.slice(Lo * f0, Lo * (f0 + step)).to_host()
+        assert bits_equal(a, b), f"frames {f0}..{f0 + step}"
+    for fr in (0, frames - 1):
+        xin = x.slice(n * fr, n * (fr + 1)).to_host()
+        sp = spec.slice(n * fr, n * (fr + 1)).to_host()
+        truth = oracle.fft_f64_frames(xin.astype(np.complex128), n, +1) / np.sqrt(float(n))
+        assert oracle.evm_db(sp, truth) <= -120.0
+        assert bits_equal(one.slice(Lo * fr, Lo * (fr + 1)).to_host(), oracle.interpolate(sp, nb))
